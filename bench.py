@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark: cells/sec of encode + kNN (BASELINE.json metric).
+
+Workload (config 3 of BASELINE.json): synthetic 100k cells x 30k genes (5 % dense
+integer counts), `cont` BiGAN encoder (30000 -> 3000 -> [3000+30000] -> 1500 ->
+BN -> 150 -> 150 -> 64, random Glorot weights), exact k=15 kNN on the encodings.
+A step = one pass of the whole hot path: device-resident CSR -> gather -> encoder
+-> (all-gather) -> kNN -> encodings + neighbour ids on the host.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+With N > 1 the 100k cells are split into N contiguous blocks (strong scaling), one
+process per GPU, one RCCL all-gather of encodings per step.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--cells', type=int, default=100000)
+    ap.add_argument('--genes', type=int, default=30000)
+    ap.add_argument('--latent', type=int, default=64)
+    ap.add_argument('--k', type=int, default=15)
+    ap.add_argument('--arch', default='cont')
+    ap.add_argument('--batch-rows', type=int, default=0, help='rows per pass through the layer stack (0 = library default)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-sample-cells', type=int, default=2048)
+    ap.add_argument('--cpu-sample-knn', type=int, default=20000)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, enc, local, enc_host):
+    """The oracle (a CPU port of the path; the reference's TF code cannot run here or on the
+    GPU box) timed on this host's cores on a bounded sample of the same workload."""
+    import ctypes
+    from cellcomm_amd import _lib
+    from oracle import encoder_oracle as eo
+    from oracle import knn_oracle as ko
+    ns = min(args.cpu_sample_cells, local.shape[0])
+    ld = (args.genes + 31) // 32 * 32
+    dense = np.empty((ns, ld), dtype=np.float32)
+    _lib.check(_lib.lib().cc_gather_dense(local.device_handle(), None, 0, ns, ld, dense.ctypes.data, 0))
+    dense = np.ascontiguousarray(dense[:, :args.genes])
+    ws = enc.get_weights()
+    t0 = time.perf_counter()
+    out = eo.forward(args.arch, ws, dense, np.float32)              # one batch, all cores (BLAS sgemm)
+    t_enc = time.perf_counter() - t0
+    nb = min(256, ns)
+    t0 = time.perf_counter()
+    eo.predict_like_keras(args.arch, ws, dense[:nb])                # batches of 32, as keras predict
+    t_b32 = (time.perf_counter() - t0) / nb
+    nk = min(args.cpu_sample_knn, enc_host.shape[0])
+    t0 = time.perf_counter()
+    ko.knn(enc_host[:nk], args.k)
+    t_knn = time.perf_counter() - t0
+    per_pair = t_knn / (nk * nk)
+    per_cell = t_enc / ns + per_pair * args.cells
+    rel = float(np.max(np.abs(out - enc_host[:ns]) / np.abs(out))) if local.row_ids() is None else None
+    return {
+        'value': 1.0 / per_cell, 'unit': 'cells/s', 'cores': os.cpu_count(), 'kind': 'port',
+        'sample': f'oracle fp32 NumPy/BLAS forward on {ns} cells x {args.genes} genes in one batch '
+                  f'({t_enc:.2f} s) + oracle/knn_oracle.c (OpenMP) on {nk} x {nk} encodings ({t_knn:.2f} s), '
+                  f'kNN cost scaled per candidate pair to {args.cells} candidates',
+        'encode_cells_per_s': ns / t_enc,
+        'encode_cells_per_s_batch32_like_keras_predict': 1.0 / t_b32,
+        'knn_pairs_per_s': 1.0 / per_pair,
+        'gpu_vs_cpu_sample_max_rel': rel,
+    }
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit(f'--gpus {args.gpus} needs one process per GPU: launch with '
+                             f'python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+
+    import cellcomm_amd as cc
+    from cellcomm_amd import _lib, pipeline, synth
+    _lib.ensure_init(local_rank)
+
+    lo, hi = pipeline.shard_bounds(args.cells, world, rank)
+    # every rank draws the same global stream and keeps its block, so the union is the N=1 input
+    local, _keep = synth.synth_csr_device(hi - lo, args.genes, density=0.05, seed=1234 + rank)
+    enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321,
+                        batch_rows=args.batch_rows or None)
+    backend = pipeline.HipBackend()
+    host_enc = np.empty((hi - lo, args.latent), dtype=np.float32)
+
+    def step():
+        res = pipeline.encode_and_knn(enc, local, args.k, backend=backend)
+        q0 = res['q_begin']
+        host_enc[:] = res['encodings'][q0:q0 + (hi - lo)].cpu().numpy()
+        return res
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = _lib.profile_snapshot()
+    _lib.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        g1 = prof['gemm_l1']
+        avg_ms = g1['ms'] / max(g1['launches'], 1)
+        flop_per_launch = g1['work'] / max(g1['launches'], 1)
+        achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
+        stages = {k: {'launches': v['launches'], 'ms_per_step': v['ms'] / args.steps,
+                      'rate': (v['work'] / (v['ms'] * 1e-3)) if v['ms'] > 0 else 0.0}
+                  for k, v in prof.items() if v['launches']}
+        line = {
+            'metric': 'cells/sec encode+kNN, 100k cells x 30k genes', 'value': args.cells * args.steps / elapsed,
+            'unit': 'cells/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'BASELINE configs[2]: synthetic {args.cells} cells x {args.genes} genes (5% dense '
+                                   f'integer counts), {args.arch} encoder latent={args.latent} (random Glorot weights), '
+                                   f'exact k={args.k} brute-force kNN',
+                       'cells': args.cells, 'genes': args.genes, 'latent': args.latent, 'k': args.k,
+                       'arch': args.arch, 'parallelism': f'cells sharded over {world} GPU(s), 1 all-gather/step',
+                       'knn_fallback_queries_rank0': int(_lib.lib().cc_knn_last_fallback_count())},
+            'roofline': {'kernel': 'gemm_bias_act_kernel (encoder layer 1, x[B x 30000] @ K1[30000 x 3000])',
+                         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch},
+            'stages_rank0': stages,
+        }
+        gather = prof['gather']
+        if gather['ms'] > 0:
+            gbs = gather['work'] / (gather['ms'] * 1e-3) / 1e9
+            line['roofline_gather'] = {'kernel': 'csr_gather_kernel', 'bound': 'hbm', 'achieved': gbs,
+                                       'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS}
+        if world == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args, enc, local, host_enc)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

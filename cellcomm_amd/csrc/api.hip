@@ -1,0 +1,527 @@
+// C ABI of libcellcomm_hip.so — see include/cellcomm_hip.h for the contract and
+// the reference interfaces each entry point stands in for.
+#include <cmath>
+#include <mutex>
+
+#include "common.h"
+
+namespace cc {
+
+static thread_local std::string g_err;
+static hipStream_t g_stream = nullptr;
+static int g_device = -1;
+
+void set_error(const char *fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+hipStream_t stream() { return g_stream; }
+bool initialised() { return g_stream != nullptr; }
+
+// ---- profiling ---------------------------------------------------------------
+struct ProfRec { int klass; double work; hipEvent_t e0, e1; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_pending;
+static int64_t g_launches[CC_PROF_NUM];
+static double g_ms[CC_PROF_NUM], g_work[CC_PROF_NUM];
+
+ProfScope::ProfScope(int klass_, double work_) : klass(klass_), work(work_) {
+  if (!g_prof_on) return;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+  (void)hipEventRecord(e0, g_stream);
+}
+ProfScope::~ProfScope() {
+  if (!e0 || !e1) return;
+  (void)hipEventRecord(e1, g_stream);
+  g_pending.push_back({klass, work, e0, e1});
+}
+static void prof_drain() {
+  if (g_pending.empty()) return;
+  (void)hipStreamSynchronize(g_stream);
+  for (auto &r : g_pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
+      g_launches[r.klass] += 1;
+      g_ms[r.klass] += ms;
+      g_work[r.klass] += r.work;
+    }
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  g_pending.clear();
+}
+
+// ---- CSR handle ------------------------------------------------------------------
+struct Csr {
+  int64_t *indptr = nullptr;
+  int32_t *indices = nullptr;
+  float *vals = nullptr;
+  int64_t n_rows = 0, nnz = 0;
+  int G = 0;
+  bool owned = false;
+};
+
+// ---- encoder handle ----------------------------------------------------------------
+struct WShape { int64_t rows, cols; };
+
+struct Encoder {
+  int arch = 0, G = 0, E = 0;
+  int64_t w0 = 0, w1 = 0;  // hidden widths of the first two layers
+  int64_t batch = 8192;
+  std::vector<WShape> shapes;
+  std::vector<std::vector<float>> w;
+  std::vector<bool> have;
+  bool dirty = true;
+  PackedWeight L[5];
+  int nlayers = 0;
+  // workspace
+  int64_t ws_rows = 0;
+  int64_t ldx = 0, ld1 = 0, ld2 = 0, ld3 = 0;
+  float *x = nullptr, *h1 = nullptr, *h2 = nullptr, *h3 = nullptr, *h4 = nullptr;
+  int64_t *d_row_ids = nullptr;
+};
+
+static int64_t pad32(int64_t v) { return v == 0 ? 32 : round_up(v, GEMM_BK); }
+
+static void encoder_shapes(Encoder *e) {
+  const int64_t G = e->G, E = e->E;
+  if (e->arch == CC_ARCH_CONT) {
+    // reference src/bigan_cont.py:29 — int(gene_size * f) for f in [0.1, 0.05]
+    e->w0 = (int64_t)((double)G * 0.1);
+    e->w1 = (int64_t)((double)G * 0.05);
+    e->shapes = {{G, e->w0}, {e->w0, 0}, {e->w0 + G, e->w1}, {e->w1, 0}, {e->w1, 0}, {e->w1, 0},
+                 {e->w1, 0}, {e->w1, 0}, {e->w1, 150}, {150, 0}, {150, 150}, {150, 0}, {150, E}, {E, 0}};
+    e->nlayers = 5;
+  } else {
+    // reference src/bigan_classify.py:31-39
+    e->w0 = 1000;
+    e->w1 = 300;
+    e->shapes = {{G, 1000}, {1000, 0}, {1000, 300}, {300, 0}, {1300, 150}, {150, 0}, {150, E}, {E, 0}};
+    e->nlayers = 4;
+  }
+  e->w.assign(e->shapes.size(), {});
+  e->have.assign(e->shapes.size(), false);
+}
+
+static int encoder_pack(Encoder *e) {
+  for (size_t i = 0; i < e->have.size(); ++i)
+    if (!e->have[i]) {
+      set_error("encoder weight %zu has not been set", i);
+      return CC_ESTATE;
+    }
+  int rc;
+  if (e->arch == CC_ARCH_CONT) {
+    if ((rc = pack_weight(e->w[0].data(), e->w[1].data(), e->G, 0, e->w0, &e->L[0]))) return rc;
+    if ((rc = pack_weight(e->w[2].data(), e->w[3].data(), e->w0, e->G, e->w1, &e->L[1]))) return rc;
+    // BatchNormalization at inference (keras defaults, epsilon = 1e-3) folded into
+    // the next Dense:  (h·inv + shift) @ K3 + b3 = h @ (diag(inv) K3) + (b3 + shift @ K3)
+    const int64_t w1 = e->w1;
+    std::vector<float> k3(e->w[8].size()), b3(150);
+    std::vector<double> inv(w1), shift(w1);
+    for (int64_t i = 0; i < w1; ++i) {
+      inv[i] = (double)e->w[4][i] / std::sqrt((double)e->w[7][i] + 1e-3);
+      shift[i] = (double)e->w[5][i] - (double)e->w[6][i] * inv[i];
+    }
+    for (int64_t j = 0; j < 150; ++j) {
+      double acc = (double)e->w[9][j];
+      for (int64_t i = 0; i < w1; ++i) acc += shift[i] * (double)e->w[8][i * 150 + j];
+      b3[j] = (float)acc;
+    }
+    for (int64_t i = 0; i < w1; ++i)
+      for (int64_t j = 0; j < 150; ++j) k3[i * 150 + j] = (float)(inv[i] * (double)e->w[8][i * 150 + j]);
+    if ((rc = pack_weight(k3.data(), b3.data(), w1, 0, 150, &e->L[2]))) return rc;
+    if ((rc = pack_weight(e->w[10].data(), e->w[11].data(), 150, 0, 150, &e->L[3]))) return rc;
+    if ((rc = pack_weight(e->w[12].data(), e->w[13].data(), 150, 0, e->E, &e->L[4]))) return rc;
+  } else {
+    if ((rc = pack_weight(e->w[0].data(), e->w[1].data(), e->G, 0, 1000, &e->L[0]))) return rc;
+    if ((rc = pack_weight(e->w[2].data(), e->w[3].data(), 1000, 0, 300, &e->L[1]))) return rc;
+    if ((rc = pack_weight(e->w[4].data(), e->w[5].data(), 300, 1000, 150, &e->L[2]))) return rc;
+    if ((rc = pack_weight(e->w[6].data(), e->w[7].data(), 150, 0, e->E, &e->L[3]))) return rc;
+  }
+  e->dirty = false;
+  return CC_OK;
+}
+
+static void encoder_free_ws(Encoder *e) {
+  float **bufs[] = {&e->x, &e->h1, &e->h2, &e->h3, &e->h4};
+  for (auto b : bufs) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  if (e->d_row_ids) (void)hipFree(e->d_row_ids);
+  e->d_row_ids = nullptr;
+  e->ws_rows = 0;
+}
+
+static int alloc_zero(float **p, int64_t rows, int64_t ld) {
+  const size_t bytes = sizeof(float) * (size_t)(rows * ld);
+  CC_HIP(hipMalloc(p, bytes));
+  CC_HIP(hipMemsetAsync(*p, 0, bytes, stream()));
+  return CC_OK;
+}
+
+static int encoder_ensure_ws(Encoder *e, int64_t rows) {
+  if (rows <= e->ws_rows) return CC_OK;
+  encoder_free_ws(e);
+  e->ldx = pad32(e->G);
+  e->ld1 = pad32(e->w0);
+  e->ld2 = pad32(e->w1);
+  e->ld3 = 160;
+  int rc;
+  if ((rc = alloc_zero(&e->x, rows, e->ldx))) return rc;
+  if ((rc = alloc_zero(&e->h1, rows, e->ld1))) return rc;
+  if ((rc = alloc_zero(&e->h2, rows, e->ld2))) return rc;
+  if ((rc = alloc_zero(&e->h3, rows, e->ld3))) return rc;
+  if ((rc = alloc_zero(&e->h4, rows, e->ld3))) return rc;
+  CC_HIP(hipMalloc(&e->d_row_ids, sizeof(int64_t) * (size_t)rows));
+  e->ws_rows = rows;
+  return CC_OK;
+}
+
+// Layer stack on M dense rows already in e->x; writes out[M x E] (device).
+static int encoder_forward(Encoder *e, int64_t M, float *out) {
+  int rc;
+  if (e->arch == CC_ARCH_CONT) {
+    // reference src/bigan_cont.py:32-41 (Dropout = identity at inference)
+    if ((rc = launch_gemm(e->x, e->ldx, nullptr, 0, M, e->L[0], e->h1, e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
+    if ((rc = launch_gemm(e->h1, e->ld1, e->x, e->ldx, M, e->L[1], e->h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->h2, e->ld2, nullptr, 0, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], e->h4, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h4, e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+  } else {
+    // reference src/bigan_classify.py:31-39: p → h → concat[h, p] → 150 → softmax(E)
+    if ((rc = launch_gemm(e->x, e->ldx, nullptr, 0, M, e->L[0], e->h1, e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
+    if ((rc = launch_gemm(e->h1, e->ld1, nullptr, 0, M, e->L[1], e->h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->h2, e->ld2, e->h1, e->ld1, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_row_softmax(out, M, e->E, e->E))) return rc;
+  }
+  return CC_OK;
+}
+
+static int check_rows(const Csr *c, const int64_t *row_ids, int64_t row_start, int64_t n) {
+  CC_REQUIRE(n >= 0, "negative row count");
+  if (row_ids) {
+    for (int64_t i = 0; i < n; ++i)
+      CC_REQUIRE(row_ids[i] >= 0 && row_ids[i] < c->n_rows, "row id %lld at position %lld outside [0,%lld)",
+                 (long long)row_ids[i], (long long)i, (long long)c->n_rows);
+  } else {
+    CC_REQUIRE(row_start >= 0 && row_start + n <= c->n_rows, "rows [%lld,+%lld) outside [0,%lld)",
+               (long long)row_start, (long long)n, (long long)c->n_rows);
+  }
+  return CC_OK;
+}
+
+static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t row_start, int64_t n,
+                          float *dev_out) {
+  CC_REQUIRE(initialised(), "cc_init has not been called");
+  CC_REQUIRE(c->G == e->G, "matrix has %d genes, encoder expects %d", c->G, e->G);
+  int rc;
+  if ((rc = check_rows(c, row_ids, row_start, n))) return rc;
+  if (e->dirty && (rc = encoder_pack(e))) return rc;
+  if (n == 0) return CC_OK;
+  const int64_t B = n < e->batch ? n : e->batch;
+  if ((rc = encoder_ensure_ws(e, B))) return rc;
+  const double nnz_per_row = c->n_rows ? (double)c->nnz / (double)c->n_rows : 0.0;
+  for (int64_t off = 0; off < n; off += B) {
+    const int64_t m = (n - off < B) ? n - off : B;
+    const int64_t *d_ids = nullptr;
+    if (row_ids) {
+      CC_HIP(hipMemcpyAsync(e->d_row_ids, row_ids + off, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, stream()));
+      d_ids = e->d_row_ids;
+    }
+    if ((rc = launch_gather(c->indptr, c->indices, c->vals, d_ids, row_start + off, m, e->G, e->ldx, e->x,
+                            nnz_per_row * (double)m)))
+      return rc;
+    if ((rc = encoder_forward(e, m, dev_out + off * e->E))) return rc;
+  }
+  CC_HIP(hipStreamSynchronize(stream()));
+  return CC_OK;
+}
+
+}  // namespace cc
+
+using namespace cc;
+
+extern "C" {
+
+int cc_version(void) { return 100; }
+const char *cc_last_error(void) { return g_err.c_str(); }
+
+int cc_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int cc_init(int device) {
+  int n = 0;
+  CC_HIP(hipGetDeviceCount(&n));
+  CC_REQUIRE(device >= 0 && device < n, "device %d not available (%d HIP devices visible)", device, n);
+  CC_HIP(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  CC_HIP(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+    return CC_EHIP;
+  }
+  if (g_stream && g_device == device) return CC_OK;
+  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+  CC_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  g_device = device;
+  return CC_OK;
+}
+
+int cc_device_name(char *buf, int buflen) {
+  CC_REQUIRE(initialised(), "cc_init has not been called");
+  hipDeviceProp_t prop;
+  CC_HIP(hipGetDeviceProperties(&prop, g_device));
+  snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+  return CC_OK;
+}
+
+int cc_synchronize(void) {
+  CC_REQUIRE(initialised(), "cc_init has not been called");
+  CC_HIP(hipStreamSynchronize(g_stream));
+  return CC_OK;
+}
+
+// ---- encoder -----------------------------------------------------------------------
+int cc_encoder_create(int arch, int G, int E, int dtype, void **enc) {
+  CC_REQUIRE(enc != nullptr, "enc is NULL");
+  CC_REQUIRE(arch == CC_ARCH_CONT || arch == CC_ARCH_CLS, "unknown encoder arch %d", arch);
+  CC_REQUIRE(dtype == CC_DTYPE_F32, "unsupported dtype %d (only float32)", dtype);
+  CC_REQUIRE(G >= 1 && E >= 1, "gene_size=%d and encoding_size=%d must be >= 1", G, E);
+  Encoder *e = new Encoder();
+  e->arch = arch; e->G = G; e->E = E;
+  encoder_shapes(e);
+  *enc = e;
+  return CC_OK;
+}
+
+void cc_encoder_free(void *enc) {
+  if (!enc) return;
+  Encoder *e = static_cast<Encoder *>(enc);
+  encoder_free_ws(e);
+  for (auto &l : e->L) free_weight(&l);
+  delete e;
+}
+
+int cc_encoder_num_weights(void *enc) { return (int)static_cast<Encoder *>(enc)->shapes.size(); }
+
+int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols) {
+  Encoder *e = static_cast<Encoder *>(enc);
+  CC_REQUIRE(idx >= 0 && idx < (int)e->shapes.size(), "weight index %d out of range", idx);
+  *rows = e->shapes[idx].rows;
+  *cols = e->shapes[idx].cols;
+  return CC_OK;
+}
+
+int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols) {
+  Encoder *e = static_cast<Encoder *>(enc);
+  CC_REQUIRE(idx >= 0 && idx < (int)e->shapes.size(), "weight index %d out of range", idx);
+  const WShape s = e->shapes[idx];
+  CC_REQUIRE(rows == s.rows && cols == s.cols, "weight %d has shape (%lld,%lld), expected (%lld,%lld)", idx,
+             (long long)rows, (long long)cols, (long long)s.rows, (long long)s.cols);
+  const int64_t count = s.rows * (s.cols ? s.cols : 1);
+  e->w[idx].assign(host, host + count);
+  e->have[idx] = true;
+  e->dirty = true;
+  return CC_OK;
+}
+
+int cc_encoder_set_batch(void *enc, int64_t batch_rows) {
+  CC_REQUIRE(batch_rows >= 1, "batch_rows must be >= 1");
+  static_cast<Encoder *>(enc)->batch = batch_rows;
+  return CC_OK;
+}
+
+// ---- CSR -----------------------------------------------------------------------------
+int cc_csr_upload(const int64_t *indptr, const int32_t *indices, const float *vals, int64_t n_rows,
+                  int64_t nnz, int G, void **csr) {
+  CC_REQUIRE(initialised(), "cc_init has not been called");
+  CC_REQUIRE(csr && indptr && n_rows >= 0 && nnz >= 0 && G >= 1, "bad CSR arguments");
+  CC_REQUIRE(indptr[0] == 0 && indptr[n_rows] == nnz, "indptr must start at 0 and end at nnz");
+  for (int64_t r = 0; r < n_rows; ++r) {
+    CC_REQUIRE(indptr[r] <= indptr[r + 1], "indptr not monotone at row %lld", (long long)r);
+    for (int64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
+      CC_REQUIRE(indices[p] >= 0 && indices[p] < G, "column %d at row %lld outside [0,%d)", indices[p], (long long)r, G);
+      CC_REQUIRE(p == indptr[r] || indices[p - 1] < indices[p], "columns of row %lld not strictly increasing",
+                 (long long)r);
+    }
+  }
+  Csr *c = new Csr();
+  c->n_rows = n_rows; c->nnz = nnz; c->G = G; c->owned = true;
+  auto fail = [&](int rc) { cc_csr_free(c); return rc; };
+  if (hipMalloc(&c->indptr, sizeof(int64_t) * (size_t)(n_rows + 1)) != hipSuccess ||
+      hipMalloc(&c->indices, sizeof(int32_t) * (size_t)(nnz ? nnz : 1)) != hipSuccess ||
+      hipMalloc(&c->vals, sizeof(float) * (size_t)(nnz ? nnz : 1)) != hipSuccess) {
+    set_error("hipMalloc failed for CSR (%lld rows, %lld nnz)", (long long)n_rows, (long long)nnz);
+    return fail(CC_ENOMEM);
+  }
+  if (hipMemcpy(c->indptr, indptr, sizeof(int64_t) * (size_t)(n_rows + 1), hipMemcpyHostToDevice) != hipSuccess ||
+      (nnz && hipMemcpy(c->indices, indices, sizeof(int32_t) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess) ||
+      (nnz && hipMemcpy(c->vals, vals, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice) != hipSuccess)) {
+    set_error("hipMemcpy failed for CSR upload");
+    return fail(CC_EHIP);
+  }
+  *csr = c;
+  return CC_OK;
+}
+
+int cc_csr_wrap_device(const int64_t *dev_indptr, const int32_t *dev_indices, const float *dev_vals,
+                       int64_t n_rows, int64_t nnz, int G, void **csr) {
+  CC_REQUIRE(initialised(), "cc_init has not been called");
+  CC_REQUIRE(csr && dev_indptr && n_rows >= 0 && nnz >= 0 && G >= 1, "bad CSR arguments");
+  Csr *c = new Csr();
+  c->indptr = const_cast<int64_t *>(dev_indptr);
+  c->indices = const_cast<int32_t *>(dev_indices);
+  c->vals = const_cast<float *>(dev_vals);
+  c->n_rows = n_rows; c->nnz = nnz; c->G = G; c->owned = false;
+  *csr = c;
+  return CC_OK;
+}
+
+void cc_csr_free(void *csr) {
+  if (!csr) return;
+  Csr *c = static_cast<Csr *>(csr);
+  if (c->owned) {
+    if (c->indptr) (void)hipFree(c->indptr);
+    if (c->indices) (void)hipFree(c->indices);
+    if (c->vals) (void)hipFree(c->vals);
+  }
+  delete c;
+}
+
+int cc_gather_dense(void *csr, const int64_t *row_ids, int64_t row_start, int64_t n, int64_t ld, void *out,
+                    int out_is_device) {
+  CC_REQUIRE(initialised(), "cc_init has not been called");
+  Csr *c = static_cast<Csr *>(csr);
+  int rc;
+  if ((rc = check_rows(c, row_ids, row_start, n))) return rc;
+  CC_REQUIRE(ld >= c->G && ld % 4 == 0, "ld=%lld must be a multiple of 4 and >= G=%d", (long long)ld, c->G);
+  if (n == 0) return CC_OK;
+  int64_t *d_ids = nullptr;
+  float *d_out = static_cast<float *>(out);
+  if (row_ids) {
+    CC_HIP(hipMalloc(&d_ids, sizeof(int64_t) * (size_t)n));
+    CC_HIP(hipMemcpyAsync(d_ids, row_ids, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, stream()));
+  }
+  if (!out_is_device) CC_HIP(hipMalloc(&d_out, sizeof(float) * (size_t)(n * ld)));
+  const double nnz_hint = c->n_rows ? (double)c->nnz / (double)c->n_rows * (double)n : 0.0;
+  rc = launch_gather(c->indptr, c->indices, c->vals, d_ids, row_start, n, c->G, ld, d_out, nnz_hint);
+  if (rc == CC_OK && !out_is_device) {
+    if (hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)(n * ld), hipMemcpyDeviceToHost, stream()) != hipSuccess) {
+      set_error("hipMemcpy D2H failed in cc_gather_dense");
+      rc = CC_EHIP;
+    }
+  }
+  if (hipStreamSynchronize(stream()) != hipSuccess && rc == CC_OK) {
+    set_error("stream synchronise failed in cc_gather_dense: %s", hipGetErrorString(hipGetLastError()));
+    rc = CC_EHIP;
+  }
+  if (d_ids) (void)hipFree(d_ids);
+  if (!out_is_device) (void)hipFree(d_out);
+  return rc;
+}
+
+int cc_encode_dev(void *enc, void *csr, const int64_t *row_ids, int64_t row_start, int64_t n, float *dev_out) {
+  return encode_csr_dev(static_cast<Encoder *>(enc), static_cast<Csr *>(csr), row_ids, row_start, n, dev_out);
+}
+
+int cc_encode(void *enc, void *csr, const int64_t *row_ids, int64_t row_start, int64_t n, float *host_out) {
+  Encoder *e = static_cast<Encoder *>(enc);
+  if (n <= 0) return encode_csr_dev(e, static_cast<Csr *>(csr), row_ids, row_start, n, nullptr);
+  float *d_out = nullptr;
+  CC_HIP(hipMalloc(&d_out, sizeof(float) * (size_t)(n * e->E)));
+  int rc = encode_csr_dev(e, static_cast<Csr *>(csr), row_ids, row_start, n, d_out);
+  if (rc == CC_OK && hipMemcpy(host_out, d_out, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost) != hipSuccess) {
+    set_error("hipMemcpy D2H failed in cc_encode");
+    rc = CC_EHIP;
+  }
+  (void)hipFree(d_out);
+  return rc;
+}
+
+int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) {
+  CC_REQUIRE(initialised(), "cc_init has not been called");
+  Encoder *e = static_cast<Encoder *>(enc);
+  CC_REQUIRE(n >= 0, "negative row count");
+  int rc;
+  if (e->dirty && (rc = encoder_pack(e))) return rc;
+  if (n == 0) return CC_OK;
+  const int64_t B = n < e->batch ? n : e->batch;
+  if ((rc = encoder_ensure_ws(e, B))) return rc;
+  float *d_out = nullptr;
+  CC_HIP(hipMalloc(&d_out, sizeof(float) * (size_t)(n * e->E)));
+  for (int64_t off = 0; off < n && rc == CC_OK; off += B) {
+    const int64_t m = (n - off < B) ? n - off : B;
+    if (hipMemcpy2DAsync(e->x, sizeof(float) * (size_t)e->ldx, host_x + off * e->G, sizeof(float) * (size_t)e->G,
+                         sizeof(float) * (size_t)e->G, (size_t)m, hipMemcpyHostToDevice, stream()) != hipSuccess) {
+      set_error("hipMemcpy2D H2D failed in cc_encode_dense");
+      rc = CC_EHIP;
+      break;
+    }
+    rc = encoder_forward(e, m, d_out + off * e->E);
+    // the staging buffer is reused by the next pass
+    if (rc == CC_OK && hipStreamSynchronize(stream()) != hipSuccess) {
+      set_error("stream synchronise failed in cc_encode_dense");
+      rc = CC_EHIP;
+    }
+  }
+  if (rc == CC_OK && hipMemcpy(host_out, d_out, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost) != hipSuccess) {
+    set_error("hipMemcpy D2H failed in cc_encode_dense");
+    rc = CC_EHIP;
+  }
+  (void)hipFree(d_out);
+  return rc;
+}
+
+// ---- kNN -------------------------------------------------------------------------------
+int cc_knn_l2_dev(const float *dev_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q, int k,
+                  int include_self, int32_t *host_idx, float *host_dist) {
+  CC_REQUIRE(initialised(), "cc_init has not been called");
+  return knn_run(dev_x, n_total, d, q_begin, n_q, k, include_self, host_idx, host_dist);
+}
+
+int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_self, int32_t *host_idx,
+              float *host_dist) {
+  CC_REQUIRE(initialised(), "cc_init has not been called");
+  CC_REQUIRE(n_total > 0 && d > 0, "knn: empty input");
+  float *d_x = nullptr;
+  CC_HIP(hipMalloc(&d_x, sizeof(float) * (size_t)(n_total * d)));
+  int rc = CC_OK;
+  if (hipMemcpy(d_x, host_x, sizeof(float) * (size_t)(n_total * d), hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("hipMemcpy H2D failed in cc_knn_l2");
+    rc = CC_EHIP;
+  }
+  if (rc == CC_OK) rc = knn_run(d_x, n_total, d, 0, n_total, k, include_self, host_idx, host_dist);
+  (void)hipFree(d_x);
+  return rc;
+}
+
+// ---- profiling ----------------------------------------------------------------------------
+int cc_profile_enable(int on) {
+  prof_drain();
+  g_prof_on = on != 0;
+  return CC_OK;
+}
+int cc_profile_reset(void) {
+  prof_drain();
+  for (int i = 0; i < CC_PROF_NUM; ++i) { g_launches[i] = 0; g_ms[i] = 0; g_work[i] = 0; }
+  return CC_OK;
+}
+int cc_profile_get(int klass, int64_t *launches, double *ms, double *work) {
+  CC_REQUIRE(klass >= 0 && klass < CC_PROF_NUM, "profile class %d out of range", klass);
+  prof_drain();
+  *launches = g_launches[klass];
+  *ms = g_ms[klass];
+  *work = g_work[klass];
+  return CC_OK;
+}
+
+}  // extern "C"

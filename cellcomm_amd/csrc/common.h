@@ -1,0 +1,81 @@
+// Shared host-side plumbing for libcellcomm_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cellcomm_hip.h"
+
+namespace cc {
+
+void set_error(const char *fmt, ...);
+hipStream_t stream();
+bool initialised();
+
+// Kernel-class timers (HIP events on the library stream).
+struct ProfScope {
+  int klass;
+  double work;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  ProfScope(int klass, double work);
+  ~ProfScope();
+};
+
+#define CC_HIP(expr)                                                              \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess) {                                                       \
+      cc::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),        \
+                    __FILE__, __LINE__);                                          \
+      return CC_EHIP;                                                             \
+    }                                                                             \
+  } while (0)
+
+#define CC_REQUIRE(cond, ...)                                                     \
+  do {                                                                            \
+    if (!(cond)) {                                                                \
+      cc::set_error(__VA_ARGS__);                                                 \
+      return CC_EINVAL;                                                           \
+    }                                                                             \
+  } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
+
+// ---- kernels' host launchers (defined in the .hip files) -------------------
+
+// gather.hip
+int launch_gather(const int64_t *d_indptr, const int32_t *d_indices, const float *d_vals,
+                  const int64_t *d_row_ids, int64_t row_start, int64_t n, int G, int64_t ld,
+                  float *d_out, double avg_nnz_hint);
+
+// gemm.hip
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32;
+enum Act { ACT_SIGMOID = 0, ACT_LINEAR = 1 };
+struct PackedWeight {
+  float *d_w = nullptr;     // [NT][KT][BK/4][BN][4]
+  float *d_bias = nullptr;  // [NT*BN] zero padded
+  int64_t K1 = 0, K2 = 0;   // logical rows of segment 1 / 2
+  int64_t KT1 = 0, KT2 = 0; // k-tiles of segment 1 / 2
+  int64_t N = 0, NT = 0;
+};
+// Pack host kernel `w` [K1+K2 x N] row-major (rows [0,K1) multiply segment 1,
+// rows [K1,K1+K2) segment 2) and bias[N] into the device layout.
+int pack_weight(const float *w, const float *bias, int64_t K1, int64_t K2, int64_t N,
+                PackedWeight *out);
+void free_weight(PackedWeight *w);
+// C[M x N] (ldc) = act(A1[M x K1](lda1) @ W[0:K1] + A2[M x K2](lda2) @ W[K1:] + bias)
+// lda* must cover KT*·BK columns and the columns beyond K* must be zero.
+int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M,
+                const PackedWeight &W, float *C, int64_t ldc, int act, int prof_class);
+int launch_row_softmax(float *X, int64_t M, int E, int64_t ld);
+
+// knn.hip
+int knn_run(const float *d_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q, int k,
+            int include_self, int32_t *h_idx, float *h_dist);
+
+}  // namespace cc

@@ -1,0 +1,80 @@
+// K1 — CSR → dense minibatch gather (HBM-bound).
+//
+// Replaces the dense pivot of load_matrix plus the row sampling of
+// CellTraining.sample_cell_data (reference src/cell_type_training.py:12-14,
+// 37-38): rows of the cell x gene matrix are kept as CSR in HBM and only the
+// rows of the current pass are densified.
+//
+// One 256-thread workgroup owns one (row, 4096-column chunk).  The chunk is
+// staged in LDS: zero-filled with 16-byte LDS stores, the row's non-zeros that
+// fall in the chunk (found by two binary searches on the row's sorted column
+// ids) are scattered into it with 4-byte LDS stores, and the chunk then leaves
+// as full, coalesced 16-byte-per-lane global stores.  HBM therefore sees one
+// streaming read of (index, value) pairs and one streaming write of the dense
+// tile; nothing is read-modify-written.  16 KiB of LDS per workgroup keeps
+// 8 workgroups (32 waves) resident per CU.
+//
+// Algorithmic bytes per cell: 8·nnz + 8 (CSR read) + 4·ld (dense write).
+#include "common.h"
+
+namespace cc {
+
+constexpr int GATHER_CH = 4096;
+constexpr int GATHER_THREADS = 256;
+
+__device__ __forceinline__ int64_t lower_bound_i32(const int32_t *__restrict__ a, int64_t lo,
+                                                   int64_t hi, int32_t key) {
+  while (lo < hi) {
+    int64_t mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(GATHER_THREADS) void csr_gather_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ vals, const int64_t *__restrict__ row_ids, int64_t row_start,
+    int nchunks, int64_t ld, float *__restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float tile[GATHER_CH];
+  const int tid = threadIdx.x;
+  const int64_t r = blockIdx.x / nchunks;
+  const int chunk = blockIdx.x % nchunks;
+  const int64_t row = row_ids ? row_ids[r] : row_start + r;
+  const int64_t c0 = (int64_t)chunk * GATHER_CH;
+  const int64_t c1 = (c0 + GATHER_CH < ld) ? c0 + GATHER_CH : ld;
+  const int64_t beg = indptr[row], end = indptr[row + 1];
+
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 *tile4 = reinterpret_cast<float4 *>(tile);
+#pragma unroll
+  for (int i = tid; i < GATHER_CH / 4; i += GATHER_THREADS) tile4[i] = z;
+
+  const int64_t lo = lower_bound_i32(indices, beg, end, (int32_t)c0);
+  const int64_t hi = lower_bound_i32(indices, lo, end, (int32_t)c1);
+  __syncthreads();
+  for (int64_t p = lo + tid; p < hi; p += GATHER_THREADS) tile[indices[p] - (int32_t)c0] = vals[p];
+  __syncthreads();
+
+  float4 *orow = reinterpret_cast<float4 *>(out + r * ld + c0);
+  const int n4 = (int)((c1 - c0) >> 2);
+#pragma unroll 4
+  for (int i = tid; i < n4; i += GATHER_THREADS) orow[i] = tile4[i];
+}
+
+int launch_gather(const int64_t *d_indptr, const int32_t *d_indices, const float *d_vals,
+                  const int64_t *d_row_ids, int64_t row_start, int64_t n, int G, int64_t ld,
+                  float *d_out, double nnz_hint) {
+  if (n == 0) return CC_OK;
+  CC_REQUIRE(ld % 4 == 0 && ld >= G, "gather: ld=%lld must be a multiple of 4 and >= G=%d",
+             (long long)ld, G);
+  const int nchunks = (int)ceil_div(ld, GATHER_CH);
+  const int64_t nblocks = n * nchunks;
+  CC_REQUIRE(nblocks < (int64_t)2147483647, "gather: grid too large (%lld blocks)", (long long)nblocks);
+  ProfScope prof(CC_PROF_GATHER, 8.0 * nnz_hint + 8.0 * (double)n + 4.0 * (double)ld * (double)n);
+  hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)nblocks), dim3(GATHER_THREADS), 0, stream(),
+                     d_indptr, d_indices, d_vals, d_row_ids, row_start, nchunks, ld, d_out);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+}  // namespace cc

@@ -1,0 +1,278 @@
+// K2/K4 — Dense layers of the BiGAN encoder as fp32 MFMA GEMMs with a fused
+// bias + activation epilogue, plus the row-softmax of the classify encoder.
+//
+// Replaces keras `layers.Dense(..., activation=tf.nn.sigmoid)` and
+// `layers.Concatenate()` of the encoder graphs (reference
+// src/bigan_cont.py:31-41, src/bigan_classify.py:29-40) at inference.
+//
+//   C[M x N] = act( A1[M x K1] @ W[0:K1] + A2[M x K2] @ W[K1:K1+K2] + bias )
+//
+// The Concatenate is never materialised: the concatenated input is expressed
+// as two K-segments (A1 then A2) of one accumulation.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32 — exact fp32 products, fp32 accumulate
+// (gfx950 has no xf32/TF32; dense fp32 matrix peak 157.3 TFLOP/s).
+//
+// Tiling: 128 x 128 output tile per 256-thread workgroup, 4 waves as 2 x 2,
+// each wave 64 x 64 = 2 x 2 MFMA tiles (64 accumulator VGPRs).  K advances in
+// steps of 32 through LDS:
+//   A tile  [128][32+4] fp32, +4 pad → ds_read_b128 of 4 consecutive k per
+//           lane is bank-conflict free (36·r mod 64 distinct for r mod 16).
+//   W tile  [8][128][4] fp32: weights are pre-packed on upload so that the 4
+//           k-values a lane feeds to 4 consecutive MFMAs are one 16-byte read
+//           and a whole 16 KiB tile is contiguous in HBM.
+// Lane (r = lane&31, h = lane>>5) of MFMA step (t,u) supplies k = 8t + 4h + u.
+// Global → register prefetch of K-step t+1 is issued before the MFMAs of step
+// t and written to LDS after them (2 barriers per K-step; 2–3 workgroups per
+// CU cover each other's barrier gaps).
+//
+// Workgroup → tile map: XCD-aware (blockIdx%8 = XCD under round-robin dispatch
+// gets a contiguous slab of tiles) with grouped ordering (8 M-tiles share each
+// W tile consecutively) so that concurrently resident tiles on one XCD re-use
+// A and W panels out of that XCD's 4 MiB L2.
+#include "common.h"
+
+namespace cc {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+
+constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
+constexpr int LDS_A_STRIDE = BK + 4;           // floats
+constexpr int GEMM_THREADS = 256;
+constexpr int TILE_W_FLOAT4 = (BK / 4) * BN;   // 1024 float4 = 16 KiB
+constexpr int GROUP_M = 8;
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+__global__ __launch_bounds__(GEMM_THREADS) void gemm_bias_act_kernel(
+    const float *__restrict__ A1, int64_t lda1, const float *__restrict__ A2, int64_t lda2,
+    int64_t M, const float4 *__restrict__ Wp, const float *__restrict__ bias, int KT1, int KT,
+    int N, int MT, int NT, float *__restrict__ C, int64_t ldc, int act) {
+  __shared__ __attribute__((aligned(16))) float lds[BM * LDS_A_STRIDE + TILE_W_FLOAT4 * 4];
+  float *As = lds;
+  float4 *Bs4 = reinterpret_cast<float4 *>(lds + BM * LDS_A_STRIDE);
+
+  // ---- workgroup → tile ---------------------------------------------------
+  const int nwg = MT * NT;
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+  const int wgid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+  const int per_group = GROUP_M * NT;
+  const int first_m = (wgid / per_group) * GROUP_M;
+  const int gsz = (MT - first_m < GROUP_M) ? MT - first_m : GROUP_M;
+  const int m_tile = first_m + (wgid % per_group) % gsz;
+  const int n_tile = (wgid % per_group) / gsz;
+  const int64_t m0 = (int64_t)m_tile * BM;
+  const int n0 = n_tile * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int r = lane & 31, h = lane >> 5;
+
+  // ---- staging addresses ----------------------------------------------------
+  const int a_row = tid >> 3;  // + 32 p
+  const int a_k4 = tid & 7;
+  int64_t a_grow[4];
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    int64_t gr = m0 + a_row + 32 * p;
+    a_grow[p] = gr < M ? gr : M - 1;
+  }
+  const float4 *Wtile = Wp + (int64_t)n_tile * KT * TILE_W_FLOAT4;
+
+  float4 ra[4], rb[4];
+  auto stage_load = [&](int kt) {
+    const float *Aseg;
+    int64_t lda, koff;
+    if (kt < KT1) { Aseg = A1; lda = lda1; koff = (int64_t)kt * BK; }
+    else { Aseg = A2; lda = lda2; koff = (int64_t)(kt - KT1) * BK; }
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      ra[p] = *reinterpret_cast<const float4 *>(Aseg + a_grow[p] * lda + koff + 4 * a_k4);
+    const float4 *wt = Wtile + (int64_t)kt * TILE_W_FLOAT4;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) rb[p] = wt[tid + GEMM_THREADS * p];
+  };
+  auto stage_write = [&]() {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+      *reinterpret_cast<float4 *>(As + (a_row + 32 * p) * LDS_A_STRIDE + 4 * a_k4) = ra[p];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) Bs4[tid + GEMM_THREADS * p] = rb[p];
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  if (KT > 0) {
+    stage_load(0);
+    stage_write();
+  }
+  __syncthreads();
+
+  const float *a_lds = As + (wm * 64 + r) * LDS_A_STRIDE + 4 * h;
+  const float4 *b_lds = Bs4 + h * BN + wn * 64 + r;
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + 1 < KT;
+    if (more) stage_load(kt + 1);
+#pragma unroll
+    for (int t = 0; t < BK / 8; ++t) {
+      float4 a[2], b[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        a[mt] = *reinterpret_cast<const float4 *>(a_lds + mt * 32 * LDS_A_STRIDE + 8 * t);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) b[nt] = b_lds[2 * t * BN + nt * 32];
+      const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
+      const float bv[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][u], bv[nt][u], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) stage_write();
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias + activation, 128-byte row segments per half-wave ------
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) {
+    const int col = n0 + wn * 64 + nt * 32 + r;
+    const bool col_ok = col < N;
+    const float bcol = col_ok ? bias[col] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int64_t row = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (col_ok && row < M) {
+          float z = acc[mt][nt][e] + bcol;
+          C[row * ldc + col] = (act == ACT_SIGMOID) ? sigmoidf_(z) : z;
+        }
+      }
+    }
+  }
+}
+
+// ---- weight packing ----------------------------------------------------------
+// dst float index f → (n_tile, kt, j, i, c): k = 4j + c within the k-tile,
+// n = n_tile·128 + i.
+__global__ void pack_weight_kernel(const float *__restrict__ w, int64_t K1, int64_t K2, int64_t N,
+                                   int64_t KT1, int64_t KT, int64_t NT, float *__restrict__ dst) {
+  const int64_t total = NT * KT * (int64_t)TILE_W_FLOAT4 * 4;
+  for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < total;
+       f += (int64_t)gridDim.x * blockDim.x) {
+    const int c = f & 3;
+    const int i = (f >> 2) & (BN - 1);
+    const int j = (f >> 9) & (BK / 4 - 1);
+    const int64_t tile = f >> 12;  // 4096 floats per tile
+    const int64_t kt = tile % KT, nt = tile / KT;
+    const int64_t n = nt * BN + i;
+    int64_t src_row;
+    bool ok;
+    if (kt < KT1) {
+      int64_t k = kt * BK + 4 * j + c;
+      ok = k < K1; src_row = k;
+    } else {
+      int64_t k = (kt - KT1) * BK + 4 * j + c;
+      ok = k < K2; src_row = K1 + k;
+    }
+    dst[f] = (ok && n < N) ? w[src_row * N + n] : 0.f;
+  }
+}
+
+void free_weight(PackedWeight *w) {
+  if (w->d_w) (void)hipFree(w->d_w);
+  if (w->d_bias) (void)hipFree(w->d_bias);
+  *w = PackedWeight();
+}
+
+int pack_weight(const float *w, const float *bias, int64_t K1, int64_t K2, int64_t N,
+                PackedWeight *out) {
+  static_assert(BN == 128 && BK == 32, "pack index math assumes 128 x 32 tiles");
+  free_weight(out);
+  out->K1 = K1; out->K2 = K2; out->N = N;
+  out->KT1 = ceil_div(K1, BK); out->KT2 = ceil_div(K2, BK);
+  out->NT = ceil_div(N, BN);
+  const int64_t KT = out->KT1 + out->KT2;
+  if (N == 0) return CC_OK;
+  const int64_t packed = out->NT * KT * (int64_t)TILE_W_FLOAT4 * 4;
+  float *d_raw = nullptr;
+  if ((K1 + K2) > 0) {
+    CC_HIP(hipMalloc(&d_raw, sizeof(float) * (size_t)((K1 + K2) * N)));
+    CC_HIP(hipMemcpyAsync(d_raw, w, sizeof(float) * (size_t)((K1 + K2) * N), hipMemcpyHostToDevice, stream()));
+  }
+  if (packed > 0) {
+    CC_HIP(hipMalloc(&out->d_w, sizeof(float) * (size_t)packed));
+    int64_t blocks = ceil_div(packed, 256);
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(pack_weight_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_raw, K1, K2, N,
+                       out->KT1, KT, out->NT, out->d_w);
+    CC_HIP(hipGetLastError());
+  }
+  CC_HIP(hipMalloc(&out->d_bias, sizeof(float) * (size_t)(out->NT * BN)));
+  CC_HIP(hipMemsetAsync(out->d_bias, 0, sizeof(float) * (size_t)(out->NT * BN), stream()));
+  CC_HIP(hipMemcpyAsync(out->d_bias, bias, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, stream()));
+  CC_HIP(hipStreamSynchronize(stream()));
+  if (d_raw) CC_HIP(hipFree(d_raw));
+  return CC_OK;
+}
+
+int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M,
+                const PackedWeight &W, float *C, int64_t ldc, int act, int prof_class) {
+  if (M == 0 || W.N == 0) return CC_OK;
+  CC_REQUIRE(W.d_bias != nullptr, "gemm: weight not packed");
+  CC_REQUIRE(W.KT1 == 0 || (A1 && lda1 >= W.KT1 * BK && lda1 % 4 == 0),
+             "gemm: segment 1 needs lda >= %lld (got %lld)", (long long)(W.KT1 * BK), (long long)lda1);
+  CC_REQUIRE(W.KT2 == 0 || (A2 && lda2 >= W.KT2 * BK && lda2 % 4 == 0),
+             "gemm: segment 2 needs lda >= %lld (got %lld)", (long long)(W.KT2 * BK), (long long)lda2);
+  const int64_t MT = ceil_div(M, BM);
+  const int64_t nwg = MT * W.NT;
+  CC_REQUIRE(nwg < (int64_t)2147483647, "gemm: grid too large");
+  ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
+  hipLaunchKernelGGL(gemm_bias_act_kernel, dim3((unsigned)nwg), dim3(GEMM_THREADS), 0, stream(), A1, lda1, A2,
+                     lda2, M, reinterpret_cast<const float4 *>(W.d_w), W.d_bias, (int)W.KT1,
+                     (int)(W.KT1 + W.KT2), (int)W.N, (int)MT, (int)W.NT, C, ldc, act);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+// ---- row softmax (classify encoder's last activation,
+//      reference src/bigan_classify.py:39) ------------------------------------
+__global__ __launch_bounds__(256) void row_softmax_kernel(float *__restrict__ X, int64_t M, int E,
+                                                           int64_t ld) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  float *x = X + row * ld;
+  float mx = -INFINITY;
+  for (int c = lane; c < E; c += 64) mx = fmaxf(mx, x[c]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float s = 0.f;
+  for (int c = lane; c < E; c += 64) s += expf(x[c] - mx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  for (int c = lane; c < E; c += 64) x[c] = expf(x[c] - mx) / s;
+}
+
+int launch_row_softmax(float *X, int64_t M, int E, int64_t ld) {
+  if (M == 0 || E == 0) return CC_OK;
+  ProfScope prof(CC_PROF_SOFTMAX, 4.0 * (double)M * E);
+  hipLaunchKernelGGL(row_softmax_kernel, dim3((unsigned)ceil_div(M, 4)), dim3(256), 0, stream(), X, M, E, ld);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+}  // namespace cc

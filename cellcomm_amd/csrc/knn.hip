@@ -1,0 +1,497 @@
+// K5 — exact brute-force squared-L2 kNN graph on latent encodings.
+//
+// The reference has no kNN code: neighbour graphs are built
+// inside UMAP/TSNE (reference src/intercepts/plot_intercepts.py:92,176,183).
+// Semantics are those of oracle/knn_oracle.c: for query i the k rows j with the
+// smallest (dist64(i,j), j), dist64 = sequential float64 sum of squared float64
+// differences; self excluded by index unless include_self.
+//
+// Three stages, bit-exact by construction:
+//  1. select  — approximate distances ‖c‖² + ‖q‖² − 2 q·c for a 32-candidate x
+//     32-query tile come straight out of one chain of v_mfma_f32_32x32x2_f32
+//     (the norms ride along as two extra K rows), one wave per 32 queries.
+//     Candidates are pre-packed so each lane's operands for 4 MFMA steps are one
+//     coalesced 16-byte load; queries stay in registers for the whole scan.
+//     Per query a running threshold τ (its K'-th best so far, K' = k + slack)
+//     filters the accumulator registers; survivors are appended to a per-query
+//     LDS list with a wavefront-local atomic, and a list that could overflow is
+//     compacted by the wave (rank-by-counting on 64-bit (dist,idx) keys).
+//  2. rerank  — the K' survivors are re-scored in float64 exactly as the oracle
+//     does and ordered by (dist64, idx).  The result is CERTIFIED when the k-th
+//     exact distance is below τ_approx(K') − ε, ε a rigorous bound on the fp32
+//     error of stage 1: every point outside the list is then provably farther.
+//  3. fallback — uncertified queries (dense duplicates / near ties) are rescanned
+//     against all candidates in float64, bounded by their stage-2 k-th key.
+#include "common.h"
+
+namespace cc {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using u64 = unsigned long long;
+
+static bool g_force_fallback = false;
+static int64_t g_last_fallback = 0;
+
+__device__ __forceinline__ unsigned f32_to_ordered(float f) {
+  unsigned b = __float_as_uint(f);
+  return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ordered_to_f32(unsigned o) {
+  unsigned b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+  return __uint_as_float(b);
+}
+
+// ---- norms -------------------------------------------------------------------
+__global__ void knn_norm_kernel(const float *__restrict__ x, int64_t N, int d, float *__restrict__ norms,
+                                unsigned *__restrict__ maxnorm_bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  double s = 0.0;
+  for (int t = 0; t < d; ++t) {
+    double v = (double)x[i * d + t];
+    s += v * v;
+  }
+  const float f = (float)s;
+  norms[i] = f;
+  atomicMax(maxnorm_bits, __float_as_uint(f));  // non-negative floats order as uints
+}
+
+// ---- candidate packing ---------------------------------------------------------
+// P[((b·NG + g)·64 + lane)·4 + u] = Aaug[32b + (lane&31)][8g + 4(lane>>5) + u]
+// Aaug[c] = [x_c[0..d), ‖x_c‖², 1, 0 …]; rows beyond N: [0…, +inf, 1, 0 …].
+__global__ void knn_pack_kernel(const float *__restrict__ x, const float *__restrict__ norms, int64_t N,
+                                int d, int NG, int64_t NB, float4 *__restrict__ P) {
+  const int64_t total = NB * NG * 64;
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= total) return;
+  const int lane = f & 63;
+  const int g = (int)((f >> 6) % NG);
+  const int64_t b = (f >> 6) / NG;
+  const int64_t cand = b * 32 + (lane & 31);
+  const int kbase = 8 * g + 4 * (lane >> 5);
+  float v[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int k = kbase + u;
+    float val = 0.f;
+    if (cand < N) {
+      if (k < d) val = x[cand * d + k];
+      else if (k == d) val = norms[cand];
+      else if (k == d + 1) val = 1.f;
+    } else {
+      if (k == d) val = INFINITY;
+      else if (k == d + 1) val = 1.f;
+    }
+    v[u] = val;
+  }
+  P[f] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// ---- stage 1: select -------------------------------------------------------------
+constexpr int SEL_MAXJ = 4;  // list capacity <= 256 entries
+
+__device__ __forceinline__ void compact_list(u64 *L, int *cnt_p, float *tau_p, int KP, int lane) {
+  const int c = *cnt_p;
+  u64 e[SEL_MAXJ];
+  int rk[SEL_MAXJ];
+#pragma unroll
+  for (int j = 0; j < SEL_MAXJ; ++j) {
+    const int idx = lane + 64 * j;
+    e[j] = (idx < c) ? L[idx] : ~0ull;
+    rk[j] = 0;
+  }
+  for (int i = 0; i < c; ++i) {
+    const u64 v = L[i];
+#pragma unroll
+    for (int j = 0; j < SEL_MAXJ; ++j)
+      if (64 * j < c) rk[j] += (v < e[j]) ? 1 : 0;
+  }
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int j = 0; j < SEL_MAXJ; ++j) {
+    const int idx = lane + 64 * j;
+    if (idx < c && rk[j] < KP) {
+      L[rk[j]] = e[j];
+      if (rk[j] == KP - 1) *tau_p = ordered_to_f32((unsigned)(e[j] >> 32));
+    }
+  }
+  if (lane == 0) *cnt_p = c < KP ? c : KP;
+  __builtin_amdgcn_wave_barrier();
+}
+
+template <int NG>
+__global__ __launch_bounds__(64) void knn_select_kernel(
+    const float4 *__restrict__ P, const float *__restrict__ norms, const float *__restrict__ x, int64_t N,
+    int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self, int KP, int CAP,
+    u64 *__restrict__ out_keys, int *__restrict__ out_cnt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  u64 *list = reinterpret_cast<u64 *>(smem);            // [32][CAP]
+  float *tau_s = reinterpret_cast<float *>(list + 32 * CAP);  // [32]
+  int *cnt = reinterpret_cast<int *>(tau_s + 32);       // [32]
+
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t ql = (int64_t)blockIdx.x * 32 + r;
+  const bool qvalid = ql < n_q;
+  const int64_t q = q_begin + ql;
+
+  float4 bq[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 8 * g + 4 * h + u;
+      float val = 0.f;
+      if (qvalid) {
+        if (k < d) val = -2.0f * x[q * d + k];
+        else if (k == d) val = 1.f;
+        else if (k == d + 1) val = norms[q];
+      }
+      v[u] = val;
+    }
+    bq[g] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  if (lane < 32) {
+    cnt[r] = 0;
+    tau_s[r] = qvalid ? INFINITY : -INFINITY;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float tau = tau_s[r];
+  const int self = (include_self || !qvalid) ? -1 : (int)q;
+  const int cap_guard = CAP - 32;
+
+  float4 a[NG], an[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) a[g] = P[(int64_t)g * 64 + lane];
+
+  for (int64_t b = 0; b < NB; ++b) {
+    {
+      const int64_t bn = (b + 1 < NB) ? b + 1 : b;  // last step re-reads its own block
+#pragma unroll
+      for (int g = 0; g < NG; ++g) an[g] = P[(bn * NG + g) * 64 + lane];
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, bq[g].x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, bq[g].y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, bq[g].z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, bq[g].w, acc, 0, 0, 0);
+    }
+    bool any = false;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) any |= (acc[e] <= tau);
+    if (__any(any)) {
+      const int cbase = (int)(b * 32) + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        if (acc[e] <= tau) {
+          const int cand = cbase + (e & 3) + 8 * (e >> 2);
+          if (cand < N && cand != self) {
+            const int slot = atomicAdd(&cnt[r], 1);
+            list[r * CAP + slot] = ((u64)f32_to_ordered(acc[e]) << 32) | (unsigned)cand;
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      u64 need = __ballot(lane < 32 && cnt[r] > cap_guard);
+      while (need) {
+        const int qi = __builtin_ctzll(need);
+        need &= need - 1;
+        compact_list(list + qi * CAP, cnt + qi, tau_s + qi, KP, lane);
+      }
+      tau = tau_s[r];
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) a[g] = an[g];
+  }
+
+  // final: sort every list, emit the best KP keys per query
+  for (int qi = 0; qi < 32; ++qi) {
+    compact_list(list + qi * CAP, cnt + qi, tau_s + qi, KP, lane);
+    const int64_t qo = (int64_t)blockIdx.x * 32 + qi;
+    if (qo < n_q) {
+      const int c = cnt[qi];
+      for (int i = lane; i < c; i += 64) out_keys[qo * KP + i] = list[qi * CAP + i];
+      if (lane == 0) out_cnt[qo] = c;
+    }
+  }
+}
+
+// ---- exact float64 distance, bit-for-bit the oracle's expression ------------------
+__device__ __forceinline__ double exact_dist(const double *__restrict__ xq, const float *__restrict__ xc, int d) {
+  double s = 0.0;
+  for (int t = 0; t < d; ++t) {
+    const double diff = __dsub_rn(xq[t], (double)xc[t]);
+    s = __dadd_rn(s, __dmul_rn(diff, diff));
+  }
+  return s;
+}
+
+__device__ __forceinline__ bool key_less(double da, int ia, double db, int ib) {
+  return da < db || (da == db && ia < ib);
+}
+
+// ---- stage 2: rerank + certificate ----------------------------------------------------
+// one wave per query; dynamic LDS per wave: double xq[d], double dd[KP], int ii[KP]
+__global__ __launch_bounds__(256) void knn_rerank_kernel(
+    const float *__restrict__ x, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
+    int d, int64_t q_begin, int64_t n_q, const u64 *__restrict__ keys, const int *__restrict__ cnts, int KP,
+    int k, double eps_coef, int force_flag, int32_t *__restrict__ out_idx, float *__restrict__ out_dist,
+    int *__restrict__ nflag, int *__restrict__ flagged, double *__restrict__ bound_d,
+    int *__restrict__ bound_i) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t ql = (int64_t)blockIdx.x * 4 + wave;
+  if (ql >= n_q) return;
+  const size_t per_wave = sizeof(double) * (size_t)(d + KP) + sizeof(int) * (size_t)KP;
+  char *base = smem + (size_t)wave * ((per_wave + 15) / 16 * 16);
+  double *xq = reinterpret_cast<double *>(base);
+  double *dd = xq + d;
+  int *ii = reinterpret_cast<int *>(dd + KP);
+  const int64_t q = q_begin + ql;
+  for (int t = lane; t < d; t += 64) xq[t] = (double)x[q * d + t];
+  __builtin_amdgcn_wave_barrier();
+  const int c = cnts[ql];
+  for (int j = lane; j < c; j += 64) {
+    const int cand = (int)(unsigned)(keys[ql * KP + j] & 0xffffffffull);
+    dd[j] = exact_dist(xq, x + (int64_t)cand * d, d);
+    ii[j] = cand;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j < c; j += 64) {
+    const double dj = dd[j];
+    const int ij = ii[j];
+    int rk = 0;
+    for (int i = 0; i < c; ++i) rk += key_less(dd[i], ii[i], dj, ij) ? 1 : 0;
+    if (rk < k) {
+      out_idx[ql * k + rk] = ij;
+      out_dist[ql * k + rk] = (float)dj;
+    }
+    if (rk == k - 1) {
+      bool certified;
+      if (c < KP) {
+        certified = true;  // every admissible point is in the list
+      } else {
+        const float tau = ordered_to_f32((unsigned)(keys[ql * KP + KP - 1] >> 32));
+        const double eps = eps_coef * ((double)norms[q] + (double)__uint_as_float(*maxnorm_bits));
+        certified = dj < (double)tau - eps;
+      }
+      if (!certified || force_flag) {
+        const int pos = atomicAdd(nflag, 1);
+        flagged[pos] = (int)ql;
+        bound_d[ql] = force_flag ? INFINITY : dj;
+        bound_i[ql] = force_flag ? 0x7fffffff : ij;
+      }
+    }
+  }
+}
+
+// ---- stage 3: float64 fallback scan ------------------------------------------------------
+constexpr int FB_THREADS = 256;
+constexpr int FB_CAP = 2048;
+constexpr int FB_PER_THREAD = FB_CAP / FB_THREADS;
+
+__global__ __launch_bounds__(FB_THREADS) void knn_exact_scan_kernel(
+    const float *__restrict__ x, int64_t N, int d, int64_t q_begin, const int *__restrict__ flagged,
+    const double *__restrict__ bound_d, const int *__restrict__ bound_i, int k, int include_self,
+    int32_t *__restrict__ out_idx, float *__restrict__ out_dist) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  double *bd = reinterpret_cast<double *>(smem);         // [FB_CAP]
+  double *xq = bd + FB_CAP;                              // [d]
+  double &s_bound_d = xq[d];
+  int *bi = reinterpret_cast<int *>(xq + d + 1);         // [FB_CAP]
+  int &s_cnt = bi[FB_CAP];
+  int &s_bound_i = bi[FB_CAP + 1];
+
+  const int tid = threadIdx.x;
+  const int64_t ql = flagged[blockIdx.x];
+  const int64_t q = q_begin + ql;
+  for (int t = tid; t < d; t += FB_THREADS) xq[t] = (double)x[q * d + t];
+  if (tid == 0) {
+    s_cnt = 0;
+    s_bound_d = bound_d[ql];
+    s_bound_i = bound_i[ql];
+  }
+  __syncthreads();
+
+  auto compact = [&](bool final_pass) {
+    // rank-by-counting over the buffer; keep the k smallest keys
+    const int c = s_cnt;
+    double ed[FB_PER_THREAD];
+    int ei[FB_PER_THREAD], rk[FB_PER_THREAD];
+#pragma unroll
+    for (int j = 0; j < FB_PER_THREAD; ++j) {
+      const int idx = tid + FB_THREADS * j;
+      ed[j] = idx < c ? bd[idx] : INFINITY;
+      ei[j] = idx < c ? bi[idx] : 0x7fffffff;
+      rk[j] = 0;
+    }
+    for (int i = 0; i < c; ++i) {
+      const double di = bd[i];
+      const int ix = bi[i];
+#pragma unroll
+      for (int j = 0; j < FB_PER_THREAD; ++j)
+        if (FB_THREADS * j < c) rk[j] += key_less(di, ix, ed[j], ei[j]) ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < FB_PER_THREAD; ++j) {
+      const int idx = tid + FB_THREADS * j;
+      if (idx < c && rk[j] < k) {
+        if (final_pass) {
+          out_idx[ql * k + rk[j]] = ei[j];
+          out_dist[ql * k + rk[j]] = (float)ed[j];
+        } else {
+          bd[rk[j]] = ed[j];
+          bi[rk[j]] = ei[j];
+          if (rk[j] == k - 1) { s_bound_d = ed[j]; s_bound_i = ei[j]; }
+        }
+      }
+    }
+    if (tid == 0 && !final_pass) s_cnt = c < k ? c : k;
+    __syncthreads();
+  };
+
+  for (int64_t base = 0; base < N; base += FB_THREADS) {
+    const int64_t cand = base + tid;
+    if (cand < N && (include_self || cand != q)) {
+      const double dist = exact_dist(xq, x + cand * d, d);
+      const double bdv = s_bound_d;
+      const int biv = s_bound_i;
+      if (dist < bdv || (dist == bdv && (int)cand <= biv)) {
+        const int slot = atomicAdd(&s_cnt, 1);
+        bd[slot] = dist;
+        bi[slot] = (int)cand;
+      }
+    }
+    __syncthreads();
+    if (s_cnt > FB_CAP - FB_THREADS) compact(false);  // uniform: s_cnt read after the barrier
+  }
+  compact(true);
+}
+
+// ---- host orchestration ----------------------------------------------------------------------
+template <int NG>
+static void launch_select(int64_t nwaves, size_t lds, const float4 *P, const float *norms, const float *x,
+                          int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self, int KP,
+                          int CAP, u64 *keys, int *cnts) {
+  hipLaunchKernelGGL(knn_select_kernel<NG>, dim3((unsigned)nwaves), dim3(64), lds, stream(), P, norms, x, N, d,
+                     NB, q_begin, n_q, include_self, KP, CAP, keys, cnts);
+}
+
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    CC_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    return CC_OK;
+  }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
+int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, int k, int include_self,
+            int32_t *h_idx, float *h_dist) {
+  g_last_fallback = 0;
+  CC_REQUIRE(N > 0 && N < (int64_t)2147483000, "knn: n_total=%lld out of range", (long long)N);
+  CC_REQUIRE(d >= 1 && d <= 132, "knn: d=%d unsupported (1..132)", d);
+  CC_REQUIRE(k >= 1 && k <= 128, "knn: k=%d unsupported (1..128)", k);
+  CC_REQUIRE(q_begin >= 0 && n_q >= 0 && q_begin + n_q <= N, "knn: query range [%lld,+%lld) outside n_total=%lld",
+             (long long)q_begin, (long long)n_q, (long long)N);
+  CC_REQUIRE((int64_t)k <= N - (include_self ? 0 : 1),
+             "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k,
+             (long long)(N - (include_self ? 0 : 1)));
+  if (n_q == 0) return CC_OK;
+
+  static const int ng_opts[] = {1, 2, 3, 5, 9, 17};
+  int NG = 0;
+  for (int o : ng_opts)
+    if (8 * o >= d + 2) { NG = o; break; }
+  static const int kp_opts[] = {32, 64, 96, 128, 160};
+  int KP = 0;
+  for (int o : kp_opts)
+    if (o >= k + 14) { KP = o; break; }
+  const int CAP = KP + 64;
+  const int64_t NB = ceil_div(N, 32);
+
+  DevBuf P, norms, maxn, keys, cnts, oidx, odist, nflag, flagged, bnd_d, bnd_i;
+  int rc;
+  if ((rc = P.alloc(sizeof(float4) * (size_t)(NB * NG * 64)))) return rc;
+  if ((rc = norms.alloc(sizeof(float) * (size_t)N))) return rc;
+  if ((rc = maxn.alloc(16))) return rc;
+  if ((rc = keys.alloc(sizeof(u64) * (size_t)(n_q * KP)))) return rc;
+  if ((rc = cnts.alloc(sizeof(int) * (size_t)n_q))) return rc;
+  if ((rc = oidx.alloc(sizeof(int32_t) * (size_t)(n_q * k)))) return rc;
+  if ((rc = odist.alloc(sizeof(float) * (size_t)(n_q * k)))) return rc;
+  if ((rc = nflag.alloc(16))) return rc;
+  if ((rc = flagged.alloc(sizeof(int) * (size_t)n_q))) return rc;
+  if ((rc = bnd_d.alloc(sizeof(double) * (size_t)n_q))) return rc;
+  if ((rc = bnd_i.alloc(sizeof(int) * (size_t)n_q))) return rc;
+  CC_HIP(hipMemsetAsync(maxn.p, 0, 16, stream()));
+  CC_HIP(hipMemsetAsync(nflag.p, 0, 16, stream()));
+  CC_HIP(hipMemsetAsync(oidx.p, 0xff, sizeof(int32_t) * (size_t)(n_q * k), stream()));
+
+  {
+    ProfScope prof(CC_PROF_KNN_PACK, 0.0);
+    hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, stream(), d_x, N, d,
+                       norms.as<float>(), maxn.as<unsigned>());
+    hipLaunchKernelGGL(knn_pack_kernel, dim3((unsigned)ceil_div(NB * NG * 64, 256)), dim3(256), 0, stream(), d_x,
+                       norms.as<float>(), N, d, NG, NB, P.as<float4>());
+    CC_HIP(hipGetLastError());
+  }
+  {
+    const int64_t nwaves = ceil_div(n_q, 32);
+    const size_t lds = sizeof(u64) * 32 * (size_t)CAP + 32 * 8;
+    ProfScope prof(CC_PROF_KNN_SELECT, 2.0 * (double)n_q * (double)N * (double)d);
+#define CC_SEL(NGV)                                                                                         \
+  case NGV:                                                                                                 \
+    launch_select<NGV>(nwaves, lds, P.as<float4>(), norms.as<float>(), d_x, N, d, NB, q_begin, n_q,         \
+                       include_self, KP, CAP, keys.as<u64>(), cnts.as<int>());                              \
+    break;
+    switch (NG) {
+      CC_SEL(1) CC_SEL(2) CC_SEL(3) CC_SEL(5) CC_SEL(9) CC_SEL(17)
+      default: CC_REQUIRE(false, "knn: no kernel for NG=%d", NG);
+    }
+#undef CC_SEL
+    CC_HIP(hipGetLastError());
+  }
+  // fp32 error bound of stage 1: d+2 fma terms on |terms| summing to <= 2(‖q‖²+‖c‖²),
+  // plus the rounding of the two norms to fp32.
+  const double eps_coef = 4.0 * (double)(d + 4) * 5.9604644775390625e-08;
+  {
+    const size_t per_wave = (sizeof(double) * (size_t)(d + KP) + sizeof(int) * (size_t)KP + 15) / 16 * 16;
+    ProfScope prof(CC_PROF_KNN_RERANK, 3.0 * (double)n_q * (double)KP * (double)d);
+    hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), per_wave * 4, stream(), d_x,
+                       norms.as<float>(), maxn.as<unsigned>(), d, q_begin, n_q, keys.as<u64>(), cnts.as<int>(),
+                       KP, k, eps_coef, g_force_fallback ? 1 : 0, oidx.as<int32_t>(), odist.as<float>(),
+                       nflag.as<int>(), flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>());
+    CC_HIP(hipGetLastError());
+  }
+  int h_nflag = 0;
+  CC_HIP(hipMemcpyAsync(&h_nflag, nflag.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+  CC_HIP(hipStreamSynchronize(stream()));
+  g_last_fallback = h_nflag;
+  if (h_nflag > 0) {
+    const size_t lds = sizeof(double) * (size_t)(FB_CAP + d + 1) + sizeof(int) * (size_t)(FB_CAP + 2);
+    ProfScope prof(CC_PROF_KNN_FALLBACK, 3.0 * (double)h_nflag * (double)N * (double)d);
+    hipLaunchKernelGGL(knn_exact_scan_kernel, dim3((unsigned)h_nflag), dim3(FB_THREADS), lds, stream(), d_x, N, d,
+                       q_begin, flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>(), k, include_self,
+                       oidx.as<int32_t>(), odist.as<float>());
+    CC_HIP(hipGetLastError());
+  }
+  CC_HIP(hipMemcpyAsync(h_idx, oidx.p, sizeof(int32_t) * (size_t)(n_q * k), hipMemcpyDeviceToHost, stream()));
+  CC_HIP(hipMemcpyAsync(h_dist, odist.p, sizeof(float) * (size_t)(n_q * k), hipMemcpyDeviceToHost, stream()));
+  CC_HIP(hipStreamSynchronize(stream()));
+  return CC_OK;
+}
+
+}  // namespace cc
+
+extern "C" int cc_knn_force_fallback(int on) {
+  cc::g_force_fallback = on != 0;
+  return CC_OK;
+}
+extern "C" int64_t cc_knn_last_fallback_count(void) { return cc::g_last_fallback; }

@@ -1,0 +1,46 @@
+"""kNN graph on latent encodings (K5) — host side of cc_knn_l2 / cc_knn_l2_dev.
+
+The reference builds neighbour graphs only inside umap.UMAP / sklearn TSNE
+(reference src/intercepts/plot_intercepts.py:92,176,183); this is the exact,
+brute-force replacement the north star asks for.  Semantics: oracle/knn_oracle.c.
+"""
+import numpy as np
+
+from . import _lib
+
+
+def knn_graph(encodings, k, include_self=False):
+    """(idx int32 [n x k], dist float32 [n x k]) — for every row the k nearest
+    other rows under squared L2, ordered by (distance, index).  `encodings` is a
+    host array-like [n x d]."""
+    lib = _lib.ensure_init()
+    x = np.ascontiguousarray(encodings, dtype=np.float32)
+    if x.ndim != 2:
+        raise ValueError(f'encodings must be 2-D, got shape {x.shape}')
+    n, d = x.shape
+    idx = np.empty((n, k), dtype=np.int32)
+    dist = np.empty((n, k), dtype=np.float32)
+    _lib.check(lib.cc_knn_l2(x.ctypes.data, n, d, int(k), int(bool(include_self)), idx.ctypes.data,
+                             dist.ctypes.data))
+    return idx, dist
+
+
+def knn_graph_device(dev_ptr, n_total, d, k, q_begin=0, n_q=None, include_self=False):
+    """Same for encodings already in HBM (`dev_ptr` = device address of a
+    contiguous float32 [n_total x d]); queries are rows [q_begin, q_begin+n_q) and
+    the returned indices are global row numbers."""
+    lib = _lib.ensure_init()
+    n_q = n_total - q_begin if n_q is None else n_q
+    idx = np.empty((n_q, k), dtype=np.int32)
+    dist = np.empty((n_q, k), dtype=np.float32)
+    _lib.check(lib.cc_knn_l2_dev(dev_ptr, n_total, d, q_begin, n_q, int(k), int(bool(include_self)),
+                                 idx.ctypes.data, dist.ctypes.data))
+    return idx, dist
+
+
+def last_fallback_count():
+    return int(_lib.lib().cc_knn_last_fallback_count())
+
+
+def force_fallback(on):
+    _lib.check(_lib.lib().cc_knn_force_fallback(1 if on else 0))

@@ -1,0 +1,92 @@
+"""encode -> (all-gather) -> kNN: the whole hot path, single GPU or cell-sharded.
+
+Cells are independent through gather + encoder, so rows shard across the GPUs of
+a node (one process per GPU); the only exchange is ONE all-gather of the
+per-shard encodings (RCCL over xGMI through torch.distributed's "nccl"
+backend) before each rank searches its own queries against all candidates
+(SURVEY.md §8e).  No weight or gradient traffic, no all-reduce.
+"""
+import numpy as np
+
+
+def shard_bounds(n_total, world_size, rank):
+    """Contiguous row block of rank: ceil(n/world) rows each, tail ranks short/empty."""
+    per = -(-n_total // world_size) if world_size > 0 else n_total
+    lo = min(rank * per, n_total)
+    hi = min(lo + per, n_total)
+    return lo, hi
+
+
+class HipBackend:
+    """Compute backend of the product path: HIP kernels through the C ABI, device
+    buffers as torch tensors.  (Tests inject a different backend to exercise the
+    sharding logic on CPU with gloo; the product never does.)"""
+    device = 'cuda'
+
+    def __init__(self):
+        import torch
+        from . import _lib
+        _lib.ensure_init()
+        self.torch = torch
+        torch.cuda.set_device(_lib._INIT_DEVICE)
+
+    def alloc(self, rows, width):
+        return self.torch.empty((rows, width), dtype=self.torch.float32, device='cuda')
+
+    def encode_into(self, encoder, matrix, out):
+        n = matrix.shape[0]
+        if n:
+            encoder.predict_to_device(matrix, out.data_ptr(), 0, n)
+
+    def knn(self, enc_all, n_total, q_begin, n_q, k, include_self):
+        from .knn import knn_graph_device
+        self.torch.cuda.synchronize()           # the all-gather ran on torch's stream
+        return knn_graph_device(enc_all.data_ptr(), n_total, enc_all.shape[1], k, q_begin, n_q, include_self)
+
+
+def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, group=None):
+    """Run the hot path on this rank's block of cells.
+
+    `local_matrix` holds the rows of this rank (block `shard_bounds(n_total, world,
+    rank)` of the global matrix; the whole matrix when not distributed).
+    Returns dict(encodings=[n_total x E] tensor on the backend device (all ranks),
+    idx=[n_local x k] int32 global neighbour ids, dist=[n_local x k] float32,
+    q_begin=first global row of this rank, n_total=...).
+    """
+    backend = backend or HipBackend()
+    torch = backend.torch
+    dist = torch.distributed
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    n_local = local_matrix.shape[0]
+    width = encoder.encoding_size
+
+    if not distributed:
+        enc_all = backend.alloc(n_local, width)
+        backend.encode_into(encoder, local_matrix, enc_all)
+        idx, dst = backend.knn(enc_all, n_local, 0, n_local, k, include_self)
+        return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=0, n_total=n_local)
+
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = torch.zeros(world, dtype=torch.int64, device=backend.device)
+    mine = torch.tensor([n_local], dtype=torch.int64, device=backend.device)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    counts = counts.cpu().numpy()
+    n_total = int(counts.sum())
+    per = int(counts.max())
+    offsets = np.concatenate([[0], np.cumsum(counts)])
+    q_begin = int(offsets[rank])
+
+    enc_local = backend.alloc(per, width)
+    if n_local < per:
+        enc_local[n_local:].zero_()
+    backend.encode_into(encoder, local_matrix, enc_local)
+    gathered = backend.alloc(world * per, width)
+    if backend.device == 'cuda':
+        torch.cuda.synchronize()                # encoder ran on the library's stream
+    dist.all_gather_into_tensor(gathered, enc_local, group=group)      # the one collective
+    if all(int(c) == per for c in counts[:-1]):
+        enc_all = gathered[:n_total]            # blocks are already back to back
+    else:
+        enc_all = torch.cat([gathered[r * per:r * per + int(counts[r])] for r in range(world)]).contiguous()
+    idx, dst = backend.knn(enc_all, n_total, q_begin, n_local, k, include_self)
+    return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=q_begin, n_total=n_total)

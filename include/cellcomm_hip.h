@@ -1,0 +1,144 @@
+/*
+ * cellcomm_hip.h — C ABI of libcellcomm_hip.so (MI355X / gfx950 only).
+ *
+ * The reference (mikemey/cellcomm) has NO FFI on this path: its seam is
+ * constructor injection of an encoder factory whose product is only used
+ * through `.predict(cell_data)` (reference src/bigan_basic.py:11-21,28-30),
+ * and the kNN graph is built inside third-party UMAP/TSNE
+ * (reference src/intercepts/plot_intercepts.py:92,176,183).  The entry points
+ * below are what a ctypes stub behind that factory binds; each one names the
+ * reference behaviour it replaces.  See INTEGRATION.md for the stub.
+ *
+ * Conventions
+ *   - every function returns 0 on success, non-zero (CC_E*) on error; the
+ *     message of the last error on the calling thread is cc_last_error().
+ *   - host buffers are caller-owned, C-contiguous, row-major.
+ *   - `dev` pointers are HIP device pointers in the current process
+ *     (e.g. torch.Tensor.data_ptr()).
+ *   - handles are opaque; free them with the matching *_free.
+ *   - calls on one handle are not re-entrant; all work is issued on the
+ *     library's own HIP stream and every call returns synchronised.
+ *   - there is NO CPU fallback anywhere in this library.
+ */
+#ifndef CELLCOMM_HIP_H
+#define CELLCOMM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CC_OK 0
+#define CC_EINVAL 1   /* bad argument / shape mismatch            */
+#define CC_EHIP 2     /* HIP runtime error (message has details)  */
+#define CC_ESTATE 3   /* call order violated (e.g. weights unset) */
+#define CC_ENOMEM 4
+
+#define CC_ARCH_CONT 0 /* reference src/bigan_cont.py:28-41     */
+#define CC_ARCH_CLS 1  /* reference src/bigan_classify.py:28-40 */
+
+#define CC_DTYPE_F32 0
+
+/* ---- runtime ----------------------------------------------------------- */
+
+/* Select the HIP device used by this process and create the library stream.
+ * Fails (CC_EHIP) when no gfx950 device is visible. */
+int cc_init(int device);
+int cc_version(void);
+const char *cc_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only host); never fails. */
+int cc_device_count(void);
+int cc_device_name(char *buf, int buflen);
+int cc_synchronize(void);
+
+/* ---- encoder: replaces keras Model.predict behind
+ *      BasicBiGan.encoding_prediction (reference src/bigan_basic.py:28-30) -- */
+
+/* arch: CC_ARCH_CONT / CC_ARCH_CLS; G = gene_size, E = encoding_size. */
+int cc_encoder_create(int arch, int G, int E, int dtype, void **enc);
+void cc_encoder_free(void *enc);
+/* Number of weight arrays in Keras get_weights() order (14 cont, 8 cls) and
+ * the expected shape of array `idx` (cols == 0 for a vector). */
+int cc_encoder_num_weights(void *enc);
+int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols);
+/* Upload array `idx` (Keras order: kernels are [in x out] row-major, y = x@K+b;
+ * BatchNormalization contributes gamma, beta, moving_mean, moving_variance).
+ * reference src/bigan_cont.py:31-41, src/bigan_classify.py:29-40. */
+int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols);
+/* Rows processed per pass through the layer stack (default 8192). */
+int cc_encoder_set_batch(void *enc, int64_t batch_rows);
+
+/* ---- CSR cell x gene matrix: replaces the dense pivot of
+ *      load_matrix (reference src/cell_type_training.py:9-17) ------------- */
+
+/* indptr[n_rows+1] int64, indices[nnz] int32 (sorted, unique within a row,
+ * < G), vals[nnz] float32.  Copies to the device. */
+int cc_csr_upload(const int64_t *indptr, const int32_t *indices, const float *vals,
+                  int64_t n_rows, int64_t nnz, int G, void **csr);
+/* Adopt device-resident CSR arrays (not copied, not freed by cc_csr_free). */
+int cc_csr_wrap_device(const int64_t *dev_indptr, const int32_t *dev_indices, const float *dev_vals,
+                       int64_t n_rows, int64_t nnz, int G, void **csr);
+void cc_csr_free(void *csr);
+
+/* Densify rows into out[n x ld] float32 (ld >= G; columns [G, ld) are written
+ * as zero).  row_ids == NULL means rows row_start .. row_start+n-1, otherwise
+ * row_ids[n] (host int64) picks rows in that order — the minibatch of
+ * CellTraining.sample_cell_data (reference src/cell_type_training.py:37-38).
+ * out is a host pointer (out_is_device = 0) or a device pointer (1). */
+int cc_gather_dense(void *csr, const int64_t *row_ids, int64_t row_start, int64_t n,
+                    int64_t ld, void *out, int out_is_device);
+
+/* Encoder forward for CSR rows → host_out[n x E] float32. */
+int cc_encode(void *enc, void *csr, const int64_t *row_ids, int64_t row_start, int64_t n,
+              float *host_out);
+/* Same, result left on the device (dev_out[n x E], contiguous). */
+int cc_encode_dev(void *enc, void *csr, const int64_t *row_ids, int64_t row_start, int64_t n,
+                  float *dev_out);
+/* Encoder forward for a dense host matrix x[n x G] (what predict() receives
+ * when cell_data is a DataFrame/ndarray/list). */
+int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out);
+
+/* ---- kNN graph: no reference implementation; semantics are
+ *      defined by oracle/knn_oracle.c -------------------------------------- */
+
+/* Exact k nearest neighbours under squared L2 for queries
+ * x[q_begin .. q_begin+n_q) against all n_total rows of x[n_total x d]
+ * (float32).  Order: (distance asc, index asc); distance is the float64
+ * sequential sum of squared float64 differences, returned rounded to float32.
+ * include_self = 0 drops candidate j == query index.  idx holds GLOBAL row
+ * indices (int32).  Requires k <= n_total - (include_self ? 0 : 1). */
+int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_self,
+              int32_t *host_idx, float *host_dist);
+int cc_knn_l2_dev(const float *dev_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q,
+                  int k, int include_self, int32_t *host_idx, float *host_dist);
+/* Test hook: route every query through the float64 fallback scan. */
+int cc_knn_force_fallback(int on);
+/* Queries of the last cc_knn_* call that needed the float64 fallback scan. */
+int64_t cc_knn_last_fallback_count(void);
+
+/* ---- profiling ---------------------------------------------------------- */
+
+#define CC_PROF_GATHER 0
+#define CC_PROF_GEMM_L1 1
+#define CC_PROF_GEMM_L2 2
+#define CC_PROF_GEMM_TAIL 3
+#define CC_PROF_SOFTMAX 4
+#define CC_PROF_KNN_PACK 5
+#define CC_PROF_KNN_SELECT 6
+#define CC_PROF_KNN_RERANK 7
+#define CC_PROF_KNN_FALLBACK 8
+#define CC_PROF_NUM 9
+
+/* When enabled every kernel launch is bracketed by HIP events on the library
+ * stream; totals accumulate until cc_profile_reset(). */
+int cc_profile_enable(int on);
+int cc_profile_reset(void);
+/* Per kernel class: number of launches, summed duration in ms, and the
+ * algorithmic work (bytes for GATHER, FLOP otherwise) those launches did. */
+int cc_profile_get(int klass, int64_t *launches, double *ms, double *work);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,113 @@
+"""kNN graph on the GPU: neighbour indices bit-exact against oracle/knn_oracle.c."""
+import numpy as np
+import pytest
+
+import cellcomm_amd as cc
+from conftest import load_npz
+from cellcomm_amd import knn as hipknn
+from oracle import knn_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def check(x, k, include_self=False):
+    idx, dist = cc.knn_graph(x, k, include_self)
+    want_i, want_d = ko.knn(x, k, include_self)
+    assert idx.dtype == np.int32 and dist.dtype == np.float32
+    assert np.array_equal(idx, want_i)
+    assert np.array_equal(dist, want_d)
+    return idx
+
+
+@pytest.mark.parametrize('name', ['knn_N257_E3.npz', 'knn_N2048_E32.npz', 'knn_N2048_E64.npz'])
+@pytest.mark.parametrize('k', [15, 50])
+def test_golden_fixtures(hip, oracle_built, name, k):
+    z = load_npz(name)
+    idx, dist = cc.knn_graph(z['x'], k)
+    assert np.array_equal(idx, z[f'idx{k}'])
+    assert np.array_equal(dist, z[f'dist{k}'])
+
+
+@pytest.mark.parametrize('n,d,k', [(1000, 1, 5), (999, 2, 15), (5000, 3, 15), (3001, 8, 1), (2500, 17, 33),
+                                   (1200, 40, 64), (700, 100, 128), (600, 132, 15), (33, 64, 15), (2, 5, 1)])
+def test_shapes_and_dims(hip, oracle_built, n, d, k):
+    x = np.random.default_rng(n + d).random((n, d), dtype=np.float32)
+    check(x, k)
+
+
+def test_include_self_and_signed_data(hip, oracle_built):
+    x = np.random.default_rng(3).standard_normal((1500, 24)).astype(np.float32) * 3
+    idx = check(x, 15, include_self=True)
+    assert np.array_equal(idx[:, 0], np.arange(1500))
+    check(x, 15, include_self=False)
+
+
+def test_heavy_duplicates_need_the_fallback(hip, oracle_built):
+    # 3000 cells on 20 distinct encodings: every query has hundreds of exact ties at distance 0,
+    # far more than the K' survivors of stage 1 -> the certificate must fail and stage 3 decide.
+    rng = np.random.default_rng(8)
+    sites = rng.random((20, 16), dtype=np.float32)
+    x = sites[rng.integers(0, 20, 3000)]
+    check(x, 15)
+    assert hipknn.last_fallback_count() > 0
+    x3 = np.round(rng.random((4000, 3)) * 4).astype(np.float32) / 4      # saturated 3-d lattice (ds-style duplicates)
+    check(x3, 50)
+
+
+def test_forced_fallback_agrees(hip, oracle_built):
+    x = np.random.default_rng(4).random((1800, 32), dtype=np.float32)
+    x[100:140] = x[5]
+    hipknn.force_fallback(True)
+    try:
+        check(x, 15)
+        assert hipknn.last_fallback_count() == 1800
+        check(x, 50, include_self=True)
+    finally:
+        hipknn.force_fallback(False)
+    check(x, 15)
+    assert hipknn.last_fallback_count() < 1800
+
+
+def test_near_ties_below_fp32_resolution(hip, oracle_built):
+    # neighbours whose distances differ by far less than the fp32 error of stage 1
+    rng = np.random.default_rng(6)
+    base = rng.random((1, 64), dtype=np.float32) * 100
+    x = np.repeat(base, 600, axis=0)
+    x[:, 0] += (np.arange(600) * 1e-5).astype(np.float32)
+    x = np.concatenate([x, rng.random((600, 64), dtype=np.float32) * 100])
+    check(x, 15)
+
+
+def test_query_subrange_on_device(hip, oracle_built):
+    import torch
+    x = np.random.default_rng(12).random((3000, 64), dtype=np.float32)
+    t = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    idx, dist = hipknn.knn_graph_device(t.data_ptr(), 3000, 64, 15, q_begin=1111, n_q=777)
+    want_i, want_d = ko.knn(x, 15, q_begin=1111, n_q=777)
+    assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d)
+
+
+def test_k_too_large_is_refused(hip):
+    x = np.random.default_rng(0).random((10, 4), dtype=np.float32)
+    with pytest.raises(ValueError):
+        cc.knn_graph(x, 10)
+    assert cc.knn_graph(x, 10, include_self=True)[0].shape == (10, 10)
+    with pytest.raises(ValueError):
+        cc.knn_graph(x.ravel(), 2)
+
+
+def test_full_size_sampled_queries(hip, oracle_built):
+    # BASELINE config 3 size (100k x 64, k=15): every query is computed on the GPU, a seeded
+    # sample of 256 queries is checked bit-exact against the oracle.
+    rng = np.random.default_rng(2024)
+    x = (1.0 / (1.0 + np.exp(-rng.standard_normal((100000, 64))))).astype(np.float32)   # sigmoid-shaped
+    idx, dist = cc.knn_graph(x, 15)
+    qs = rng.choice(100000, 256, replace=False)
+    for q in qs:
+        wi, wd = ko.knn(x, 15, q_begin=int(q), n_q=1)
+        assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0])
+    # size-independent properties on all rows
+    assert np.all(idx >= 0) and np.all(idx < 100000)
+    assert np.all(idx != np.arange(100000)[:, None])
+    assert np.all(np.diff(dist, axis=1) >= 0)

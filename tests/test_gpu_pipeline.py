@@ -1,0 +1,62 @@
+"""End to end on one GPU through the reference's call surface."""
+import numpy as np
+import pytest
+
+import cellcomm_amd as cc
+from cellcomm_amd import pipeline, schema, synth
+from oracle import encoder_oracle as eo
+from oracle import knn_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def test_trainer_surface_on_example_matrix(hip, golden_dir, known):
+    data = cc.load_matrix(f'{golden_dir}/example_matrix.mtx')
+    ka = known['trainer_setup']
+    trainer = cc.CellTraining(data, 3, ka['encoding_size'], batches_per_iteration=4)
+    net = trainer.network
+    assert net.encoding_size == ka['encoding_size'] and net._encoder.input_shape == (None, ka['gene_count'])
+    enc = net.encoding_prediction(trainer.data)                 # the call at reference db_recorder.py:85
+    assert enc.shape == (5, 8) and enc.dtype == np.float32
+    truth = eo.forward('cont', net._encoder.get_weights(), data.to_dense())
+    assert np.max(np.abs(enc - truth) / np.abs(truth)) <= 1e-4
+    batch = trainer.sample_cell_data(0)
+    assert np.array_equal(net.trainings_encoding_prediction(batch), enc[[2, 0, 1]])
+    net.summary()
+    assert net.params_changed() == [False, False, False]
+    with pytest.raises(NotImplementedError):
+        trainer.run(1)
+
+
+def test_encits_document_from_gpu_encodings(hip, golden_dir):
+    data = cc.load_matrix(f'{golden_dir}/example_matrix.mtx')
+    net = cc.ContinuousCellBiGan(3, data.shape[1])
+    enc = net.encoding_prediction(data)
+    barcodes = schema.load_barcodes(f'{golden_dir}/example_barcodes.tsv')
+    doc = schema.encits_document('run', 5009, enc, barcodes, knn=cc.knn_graph(enc, 2))
+    # G=5 -> zero-width hidden layers -> all cells share one encoding -> one duplicate group of all ids
+    assert doc['cids'] == [1, 2, 3, 4, 5] and doc['ds'] == [[1, 2, 3, 4, 5]]
+    assert doc['nn'][0] == [2, 3] and doc['nn'][4] == [1, 2]
+
+
+@pytest.mark.parametrize('arch', ['cont', 'cls'])
+def test_encode_and_knn_single_gpu(hip, oracle_built, arch):
+    n, g, e, k = 1500, 2000, 32, 15
+    m = synth.synth_csr(n, g, seed=21)
+    enc = cc.HipEncoder(e, g, arch, seed=4321)
+    res = pipeline.encode_and_knn(enc, m, k)
+    got = res['encodings'].cpu().numpy()
+    truth = eo.forward(arch, enc.get_weights(), m.to_dense())
+    assert np.max(np.abs(got - truth) / np.abs(truth)) <= 1e-4
+    want_i, want_d = ko.knn(got, k)                             # bit-exact on identical inputs
+    assert np.array_equal(res['idx'], want_i) and np.array_equal(res['dist'], want_d)
+    assert res['q_begin'] == 0 and res['n_total'] == n
+
+
+def test_device_resident_csr(hip, oracle_built):
+    m_dev, (indptr, indices, values) = synth.synth_csr_device(700, 3000, seed=5)
+    host = cc.CellMatrix(indptr.cpu().numpy(), indices.cpu().numpy(), values.cpu().numpy(), 3000)
+    assert np.all(host.values >= 1) and np.all(host.values == np.round(host.values))
+    assert abs(host.nnz / (700 * 3000) - 0.05) < 0.005
+    enc = cc.HipEncoder(8, 3000, 'cont', seed=2)
+    assert np.array_equal(enc.predict(m_dev), enc.predict(host))

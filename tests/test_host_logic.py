@@ -1,0 +1,210 @@
+"""Host-side mirror of the reference interface (no GPU): loader, sampling, schema
+builders, BiGAN wrapper delegation, sharding arithmetic."""
+import os
+from unittest.mock import MagicMock
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from cellcomm_amd import bigan, matrix, pipeline, schema, synth
+from cellcomm_amd.encoder import _layer_plan, hidden_widths
+from oracle import loader_oracle as lo
+from oracle import schema_oracle as so
+
+MTX = os.path.join(GOLDEN, 'example_matrix.mtx')
+
+
+def test_load_matrix_and_pivot(known):
+    m = matrix.load_matrix(MTX)
+    assert m.shape == (5, 5)
+    assert np.array_equal(m.to_dense(), np.array(known['load_matrix']['matrix'], dtype=np.float32))
+    assert m.index.tolist() == [1, 2, 3, 4, 5] and m.columns.tolist() == [1, 2, 3, 4, 5]
+
+
+def _write_mtx(path, triplets):
+    with open(path, 'w') as f:
+        f.write('%%MatrixMarket matrix coordinate integer general\n%\n9 9 9\n')
+        for g, b, p in triplets:
+            f.write(f'{g} {b} {p}\n')
+
+
+def test_load_matrix_equals_pivot_on_ragged_input(tmp_path):
+    rng = np.random.default_rng(2)
+    trip = [(int(rng.integers(1, 60)) * 3, int(rng.integers(1, 40)) * 2, int(rng.integers(0, 9))) for _ in range(900)]
+    trip += trip[:50]                                   # exact duplicate entries -> averaged
+    trip += [(5, 7, 3), (5, 7, 8)]                      # differing duplicates -> mean 5.5
+    path = tmp_path / 'm.mtx'
+    _write_mtx(path, trip)
+    want = lo.load_matrix(path)
+    got = matrix.load_matrix(path)
+    assert got.shape == want.shape
+    assert np.array_equal(got.index, want.index.to_numpy()) and np.array_equal(got.columns, want.columns.to_numpy())
+    assert np.array_equal(got.to_dense(np.float64), want.to_numpy().astype(np.float32).astype(np.float64))
+    assert np.all(np.diff(got.indptr) >= 0)
+    for r in range(got.shape[0]):                       # canonical CSR: strictly increasing columns
+        assert np.all(np.diff(got.indices[got.indptr[r]:got.indptr[r + 1]]) > 0)
+
+
+def test_sample_cell_data_rows(known):
+    ka = known['sample_cell_data']
+    m = matrix.load_matrix(MTX)
+    sampled = m.sample(ka['batch_size'], random_state=ka['seed'])
+    assert sampled.shape == (3, 5)
+    assert sampled.row_ids().tolist() == ka['rows']
+    assert np.array_equal(sampled.to_dense(), np.array(known['load_matrix']['matrix'], dtype=np.float32)[ka['rows']])
+
+
+@pytest.mark.parametrize('seed', [0, 1, 7, 123])
+def test_sample_equals_pandas_sample(seed):
+    m = synth.synth_csr(40, 30, density=0.2, seed=seed)
+    df = m.to_dataframe()
+    want = lo.sample_cell_data(df, 11, seed)
+    got = m.sample(11, random_state=seed)
+    assert np.array_equal(got.index, want.index.to_numpy())
+    assert np.array_equal(got.to_dense(np.float64), want.to_numpy())
+    again = got.take([3, 0])                            # view of a view
+    assert np.array_equal(again.to_dense(np.float64), want.to_numpy()[[3, 0]])
+
+
+def test_load_cells_roundtrip(tmp_path):
+    m = matrix.load_matrix(MTX)
+    path = tmp_path / 'cells.csv'
+    m.to_dataframe().to_csv(path)                       # what the reference's `convert` writes
+    back = matrix.load_cells(path)
+    assert np.array_equal(back.to_dense(), m.to_dense())
+
+
+def test_synth_csr_properties():
+    m = synth.synth_csr(64, 200, density=0.05, seed=3)
+    assert m.shape == (64, 200)
+    assert set(np.unique(m.indices)) == set(range(200))            # every gene survives a pivot
+    assert m.values.min() >= 1 and m.values.max() <= 2047 and np.all(m.values == np.round(m.values))
+    for r in range(64):
+        assert np.all(np.diff(m.indices[m.indptr[r]:m.indptr[r + 1]]) > 0)
+
+
+# ---- schema ---------------------------------------------------------------------
+def test_encits_document(known):
+    ka = known['encits_document']
+    doc = schema.encits_document('run', 2009, np.array(ka['encodings']), ka['ns'])
+    assert doc == {'eid': 'run', 'it': 2009, **{k: ka[k] for k in ('cids', 'ns', 'xs', 'ys', 'zs', 'ds')}}
+    assert schema.load_barcodes(os.path.join(GOLDEN, 'example_barcodes.tsv')) == ka['ns']
+
+
+def test_schema_assertion_messages(known):
+    msg = known['messages']
+    with pytest.raises(AssertionError) as e:
+        schema.encits_document('r', 1, np.array([[], [], [], []]), ['a'] * 5)
+    assert str(e.value) == msg['length']
+    with pytest.raises(AssertionError) as e:
+        schema.encits_document('r', 1, np.array([[1, 2]] * 5), ['a'] * 5)
+    assert str(e.value) == msg['xyz']
+    with pytest.raises(ValueError) as e:
+        schema.legacy_encs_document('1', np.zeros((4, 3)), ['a'] * 5)
+    assert str(e.value) == msg['legacy_length']
+
+
+def test_duplicate_groups_equal_reference_order():
+    rng = np.random.default_rng(4)
+    enc = rng.integers(0, 4, (300, 3)).astype(np.float32) / 4      # many exact duplicates
+    coords = np.multiply(enc, 255)
+    assert schema.find_duplicate_ids(coords) == so.find_duplicate_ids(coords)
+    barcodes = [f'b{i}' for i in range(300)]
+    assert schema.encits_document('e', 5, enc, barcodes) == so.encits_document('e', 5, enc, barcodes)
+    assert schema.legacy_encs_document('7', enc, barcodes) == so.legacy_encs_document('7', enc, barcodes)
+
+
+def test_enc_file_roundtrip_and_knn_fields(tmp_path):
+    enc = np.random.default_rng(1).random((9, 3), dtype=np.float32)
+    path = tmp_path / '5009.enc'
+    schema.write_enc_file(path, enc)
+    assert np.array_equal(schema.read_enc_file(path), enc)
+    idx = np.arange(18, dtype=np.int32).reshape(9, 2) % 9
+    doc = schema.encits_document('e', 1, enc, list('abcdefghi'), knn=(idx, idx.astype(np.float32)))
+    assert doc['nn'][0] == [1, 2] and len(doc['nd']) == 9
+
+
+# ---- BiGAN wrappers ----------------------------------------------------------------
+def _mock_bigan():
+    gen, enc, disc = MagicMock(), MagicMock(), MagicMock()
+    b = bigan.BasicBiGan(encoding_size=15, gene_size=1000, generator_factory=MagicMock(return_value=gen),
+                         encoder_factory=MagicMock(return_value=enc), discriminator_factory=MagicMock(return_value=disc))
+    return b, gen, enc, disc
+
+
+def test_create_components():
+    b, gen, enc, disc = _mock_bigan()
+    assert (b._generator, b._encoder, b._discriminator) == (gen, enc, disc)
+    assert b.all_components == (gen, enc, disc) and b.encoding_size == 15
+
+
+def test_factories_called_with_sizes():
+    gf, ef, df = MagicMock(), MagicMock(), MagicMock()
+    bigan.BasicBiGan(7, 33, gf, ef, df)
+    for f in (gf, ef, df):
+        f.assert_called_once_with(7, 33)
+
+
+def test_encoding_prediction_is_pure_delegation(known):
+    ka = known['encoding_prediction_delegation']
+    b, _, enc, _ = _mock_bigan()
+    enc.predict = MagicMock(return_value=ka['prediction'])
+    assert b.encoding_prediction(ka['genes']) is enc.predict.return_value
+    enc.predict.assert_called_with(ka['genes'])
+
+
+def test_random_uniform_vector_shape():
+    b, *_ = _mock_bigan()
+    hv = b.random_uniform_vector(7)
+    assert hv.shape == (7, 15) and np.all(hv >= 0) and np.all(hv < 1)
+
+
+def test_generate_cells_rounds_injected_generator():
+    b, gen, _, _ = _mock_bigan()
+    gen.predict = MagicMock(return_value=[[0.3, 12.59939265, 2.4894546, 0.01], [0.9, 4.7007282, 0, 2.07244989]])
+    cells = b.generate_cells([[1, 0], [0, 1]], [[0.2, 0.], [0.99, 0.99]])
+    assert np.array_equal(cells, [[0, 13, 2, 0], [1, 5, 0, 2]])
+    gen.predict.assert_called_with(([[1, 0], [0, 1]], [[0.2, 0.], [0.99, 0.99]]))
+
+
+def test_absent_components_fail_loudly():
+    comp = bigan.AbsentComponent('cell_generator', 3, 5)
+    assert comp.layers == []
+    with pytest.raises(NotImplementedError):
+        comp.predict(1)
+
+
+def test_onehot_and_random_encoding_known_answers(known):
+    enc_factory = MagicMock()
+    cls = bigan.ClassifyCellBiGan(2, 4, encoder_factory=enc_factory)
+    ka = known['trainings_encoding_prediction_onehot']
+    cls.encoding_prediction = MagicMock(return_value=ka['prediction'])
+    assert np.array_equal(cls.trainings_encoding_prediction([[5, 3, 1, 4]]), np.array(ka['onehot']))
+    kr = known['random_encoding_vector']
+    np.random.seed(kr['np_seed'])
+    cls4 = bigan.ClassifyCellBiGan(kr['encoding_size'], 1, encoder_factory=MagicMock())
+    assert np.array_equal(cls4.random_encoding_vector(kr['batch']), np.array(kr['expected']))
+
+
+def test_layer_plan_matches_reference_graph(known):
+    assert hidden_widths('cont', 30000) == [3000, 1500] and hidden_widths('cont', 5) == [0, 0]
+    assert hidden_widths('cont', 11) == [1, 0] and hidden_widths('cls', 77) == [1000, 300]
+    cont = _layer_plan('cont', 12, 100)
+    cls = _layer_plan('cls', 12, 100)
+    assert cont[-1][2] == known['encoder_shapes']['cont']['last_activation']
+    assert cls[-1][2] == known['encoder_shapes']['cls']['last_activation']
+    assert [l[1] for l in cont].count('Dense') == 5 and [l[1] for l in cls].count('Dense') == 4
+    assert sorted(s for l in cont for s in l[3]) == list(range(14))
+    assert sorted(s for l in cls for s in l[3]) == list(range(8))
+
+
+# ---- sharding ------------------------------------------------------------------------
+@pytest.mark.parametrize('n,world', [(100000, 8), (10, 4), (3, 8), (0, 2), (1000000, 8), (17, 1)])
+def test_shard_bounds_partition(n, world):
+    blocks = [pipeline.shard_bounds(n, world, r) for r in range(world)]
+    assert blocks[0][0] == 0 and blocks[-1][1] == n
+    for (a, b), (c, d) in zip(blocks, blocks[1:]):
+        assert b == c and a <= b and c <= d
+    per = -(-n // world)
+    assert all(hi - lo == per for lo, hi in blocks[:-1] if hi < n)
