@@ -93,14 +93,14 @@ static void encoder_shapes(Encoder *e) {
     // reference src/bigan_cont.py:29 — int(gene_size * f) for f in [0.1, 0.05]
     e->w0 = (int64_t)((double)G * 0.1);
     e->w1 = (int64_t)((double)G * 0.05);
-    e->shapes = {{G, e->w0}, {e->w0, 0}, {e->w0 + G, e->w1}, {e->w1, 0}, {e->w1, 0}, {e->w1, 0},
-                 {e->w1, 0}, {e->w1, 0}, {e->w1, 150}, {150, 0}, {150, 150}, {150, 0}, {150, E}, {E, 0}};
+    e->shapes = {{G, e->w0}, {e->w0, -1}, {e->w0 + G, e->w1}, {e->w1, -1}, {e->w1, -1}, {e->w1, -1},
+                 {e->w1, -1}, {e->w1, -1}, {e->w1, 150}, {150, -1}, {150, 150}, {150, -1}, {150, E}, {E, -1}};
     e->nlayers = 5;
   } else {
     // reference src/bigan_classify.py:31-39
     e->w0 = 1000;
     e->w1 = 300;
-    e->shapes = {{G, 1000}, {1000, 0}, {1000, 300}, {300, 0}, {1300, 150}, {150, 0}, {150, E}, {E, 0}};
+    e->shapes = {{G, 1000}, {1000, -1}, {1000, 300}, {300, -1}, {1300, 150}, {150, -1}, {150, E}, {E, -1}};
     e->nlayers = 4;
   }
   e->w.assign(e->shapes.size(), {});
@@ -327,7 +327,7 @@ int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, 
   const WShape s = e->shapes[idx];
   CC_REQUIRE(rows == s.rows && cols == s.cols, "weight %d has shape (%lld,%lld), expected (%lld,%lld)", idx,
              (long long)rows, (long long)cols, (long long)s.rows, (long long)s.cols);
-  const int64_t count = s.rows * (s.cols ? s.cols : 1);
+  const int64_t count = s.rows * (s.cols < 0 ? 1 : s.cols);
   e->w[idx].assign(host, host + count);
   e->have[idx] = true;
   e->dirty = true;

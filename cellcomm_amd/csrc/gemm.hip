@@ -70,37 +70,54 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bias_act_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- staging addresses ----------------------------------------------------
+  // ---- staging addresses (32-bit per-thread offsets from a scalar tile base) ----
   const int a_row = tid >> 3;  // + 32 p
   const int a_k4 = tid & 7;
-  int64_t a_grow[4];
+  int a_off1[4], a_off2[4];
 #pragma unroll
   for (int p = 0; p < 4; ++p) {
     int64_t gr = m0 + a_row + 32 * p;
-    a_grow[p] = gr < M ? gr : M - 1;
+    const int lr = (int)((gr < M ? gr : M - 1) - m0);  // clamp the M tail onto a valid row
+    a_off1[p] = lr * (int)lda1 + 4 * a_k4;
+    a_off2[p] = lr * (int)lda2 + 4 * a_k4;
   }
-  const float4 *Wtile = Wp + (int64_t)n_tile * KT * TILE_W_FLOAT4;
+  const float *A1t = A1 + m0 * lda1;
+  const float *A2t = A2 + m0 * lda2;
+  const float4 *Wtile = Wp + (int64_t)n_tile * KT * TILE_W_FLOAT4 + tid;
 
-  float4 ra[4], rb[4];
-  auto stage_load = [&](int kt) {
-    const float *Aseg;
-    int64_t lda, koff;
-    if (kt < KT1) { Aseg = A1; lda = lda1; koff = (int64_t)kt * BK; }
-    else { Aseg = A2; lda = lda2; koff = (int64_t)(kt - KT1) * BK; }
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      ra[p] = *reinterpret_cast<const float4 *>(Aseg + a_grow[p] * lda + koff + 4 * a_k4);
-    const float4 *wt = Wtile + (int64_t)kt * TILE_W_FLOAT4;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) rb[p] = wt[tid + GEMM_THREADS * p];
-  };
-  auto stage_write = [&]() {
-#pragma unroll
-    for (int p = 0; p < 4; ++p)
-      *reinterpret_cast<float4 *>(As + (a_row + 32 * p) * LDS_A_STRIDE + 4 * a_k4) = ra[p];
-#pragma unroll
-    for (int p = 0; p < 4; ++p) Bs4[tid + GEMM_THREADS * p] = rb[p];
-  };
+  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+  // Global → registers for K-step kt.  No lambdas / no conditionals around the
+  // loads: the eight staging registers must stay in VGPRs (not scratch) so that
+  // the loads stay in flight behind the MFMAs of the current K-step.
+#define CC_STAGE_LOAD(kt_)                                                            \
+  {                                                                                   \
+    const int kt__ = (kt_);                                                           \
+    const bool seg1 = kt__ < KT1;                                                     \
+    const float *At = seg1 ? A1t + (int64_t)kt__ * BK : A2t + (int64_t)(kt__ - KT1) * BK; \
+    const int o0 = seg1 ? a_off1[0] : a_off2[0], o1 = seg1 ? a_off1[1] : a_off2[1];   \
+    const int o2 = seg1 ? a_off1[2] : a_off2[2], o3 = seg1 ? a_off1[3] : a_off2[3];   \
+    ra0 = *reinterpret_cast<const float4 *>(At + o0);                                 \
+    ra1 = *reinterpret_cast<const float4 *>(At + o1);                                 \
+    ra2 = *reinterpret_cast<const float4 *>(At + o2);                                 \
+    ra3 = *reinterpret_cast<const float4 *>(At + o3);                                 \
+    const float4 *wt = Wtile + (int64_t)kt__ * TILE_W_FLOAT4;                         \
+    rb0 = wt[0];                                                                      \
+    rb1 = wt[GEMM_THREADS];                                                           \
+    rb2 = wt[2 * GEMM_THREADS];                                                       \
+    rb3 = wt[3 * GEMM_THREADS];                                                       \
+  }
+#define CC_STAGE_WRITE()                                                              \
+  {                                                                                   \
+    float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;                                 \
+    *reinterpret_cast<float4 *>(aw) = ra0;                                            \
+    *reinterpret_cast<float4 *>(aw + 32 * LDS_A_STRIDE) = ra1;                        \
+    *reinterpret_cast<float4 *>(aw + 64 * LDS_A_STRIDE) = ra2;                        \
+    *reinterpret_cast<float4 *>(aw + 96 * LDS_A_STRIDE) = ra3;                        \
+    Bs4[tid] = rb0;                                                                   \
+    Bs4[tid + GEMM_THREADS] = rb1;                                                    \
+    Bs4[tid + 2 * GEMM_THREADS] = rb2;                                                \
+    Bs4[tid + 3 * GEMM_THREADS] = rb3;                                                \
+  }
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -111,8 +128,8 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bias_act_kernel(
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (KT > 0) {
-    stage_load(0);
-    stage_write();
+    CC_STAGE_LOAD(0);
+    CC_STAGE_WRITE();
   }
   __syncthreads();
 
@@ -120,8 +137,9 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bias_act_kernel(
   const float4 *b_lds = Bs4 + h * BN + wn * 64 + r;
 
   for (int kt = 0; kt < KT; ++kt) {
-    const bool more = kt + 1 < KT;
-    if (more) stage_load(kt + 1);
+    // prefetch K-step kt+1 (the last step re-reads its own tile: branch-free)
+    CC_STAGE_LOAD(kt + 1 < KT ? kt + 1 : kt);
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
 #pragma unroll
     for (int t = 0; t < BK / 8; ++t) {
       float4 a[2], b[2];
@@ -141,9 +159,11 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bias_act_kernel(
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][u], bv[nt][u], acc[mt][nt], 0, 0, 0);
     }
     __syncthreads();
-    if (more) stage_write();
+    CC_STAGE_WRITE();
     __syncthreads();
   }
+#undef CC_STAGE_LOAD
+#undef CC_STAGE_WRITE
 
   // ---- epilogue: bias + activation, 128-byte row segments per half-wave ------
 #pragma unroll

@@ -10,6 +10,9 @@
 //  1. select  — approximate distances ‖c‖² + ‖q‖² − 2 q·c for a 32-candidate x
 //     32-query tile come straight out of one chain of v_mfma_f32_32x32x2_f32
 //     (the norms ride along as two extra K rows), one wave per 32 queries.
+//     Points are first translated by the fp32 centroid μ (distances are translation
+//     invariant; ‖x−μ‖² ≪ ‖x‖² for clustered encodings, which is what makes the fp32
+//     error bound ε small enough to certify).
 //     Candidates are pre-packed so each lane's operands for 4 MFMA steps are one
 //     coalesced 16-byte load; queries stay in registers for the whole scan.
 //     Per query a running threshold τ (its K'-th best so far, K' = k + slack)
@@ -41,14 +44,37 @@ __device__ __forceinline__ float ordered_to_f32(unsigned o) {
   return __uint_as_float(b);
 }
 
-// ---- norms -------------------------------------------------------------------
-__global__ void knn_norm_kernel(const float *__restrict__ x, int64_t N, int d, float *__restrict__ norms,
-                                unsigned *__restrict__ maxnorm_bits) {
+// ---- centroid (fixed summation order: deterministic) ------------------------------
+constexpr int MEAN_BLOCKS = 256;
+__global__ void knn_colsum_kernel(const float *__restrict__ x, int64_t N, int d, double *__restrict__ partial) {
+  const int c = threadIdx.x;
+  if (c >= d) return;
+  const int64_t per = (N + MEAN_BLOCKS - 1) / MEAN_BLOCKS;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < N ? lo + per : N;
+  double s = 0.0;
+  for (int64_t i = lo; i < hi; ++i) s += (double)x[i * d + c];
+  partial[(int64_t)blockIdx.x * d + c] = s;
+}
+__global__ void knn_mean_kernel(const double *__restrict__ partial, int64_t N, int d, float *__restrict__ mu) {
+  const int c = threadIdx.x;
+  if (c >= d) return;
+  double s = 0.0;
+  for (int b = 0; b < MEAN_BLOCKS; ++b) s += partial[(int64_t)b * d + c];
+  mu[c] = (float)(s / (double)N);
+}
+
+// the one expression used everywhere for a centred coordinate (so duplicate rows stay duplicates)
+__device__ __forceinline__ float centred(float x, float mu) { return __fsub_rn(x, mu); }
+
+// ---- norms of the centred points -----------------------------------------------------
+__global__ void knn_norm_kernel(const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d,
+                                float *__restrict__ norms, unsigned *__restrict__ maxnorm_bits) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   double s = 0.0;
   for (int t = 0; t < d; ++t) {
-    double v = (double)x[i * d + t];
+    double v = (double)centred(x[i * d + t], mu[t]);
     s += v * v;
   }
   const float f = (float)s;
@@ -58,9 +84,10 @@ __global__ void knn_norm_kernel(const float *__restrict__ x, int64_t N, int d, f
 
 // ---- candidate packing ---------------------------------------------------------
 // P[((b·NG + g)·64 + lane)·4 + u] = Aaug[32b + (lane&31)][8g + 4(lane>>5) + u]
-// Aaug[c] = [x_c[0..d), ‖x_c‖², 1, 0 …]; rows beyond N: [0…, +inf, 1, 0 …].
-__global__ void knn_pack_kernel(const float *__restrict__ x, const float *__restrict__ norms, int64_t N,
-                                int d, int NG, int64_t NB, float4 *__restrict__ P) {
+// Aaug[c] = [y_c[0..d), ‖y_c‖², 1, 0 …], y = x − μ; rows beyond N: [0…, +inf, 1, 0 …].
+__global__ void knn_pack_kernel(const float *__restrict__ x, const float *__restrict__ mu,
+                                const float *__restrict__ norms, int64_t N, int d, int NG, int64_t NB,
+                                float4 *__restrict__ P) {
   const int64_t total = NB * NG * 64;
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= total) return;
@@ -75,7 +102,7 @@ __global__ void knn_pack_kernel(const float *__restrict__ x, const float *__rest
     const int k = kbase + u;
     float val = 0.f;
     if (cand < N) {
-      if (k < d) val = x[cand * d + k];
+      if (k < d) val = centred(x[cand * d + k], mu[k]);
       else if (k == d) val = norms[cand];
       else if (k == d + 1) val = 1.f;
     } else {
@@ -121,9 +148,9 @@ __device__ __forceinline__ void compact_list(u64 *L, int *cnt_p, float *tau_p, i
 
 template <int NG>
 __global__ __launch_bounds__(64) void knn_select_kernel(
-    const float4 *__restrict__ P, const float *__restrict__ norms, const float *__restrict__ x, int64_t N,
-    int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self, int KP, int CAP,
-    u64 *__restrict__ out_keys, int *__restrict__ out_cnt) {
+    const float4 *__restrict__ P, const float *__restrict__ norms, const float *__restrict__ x,
+    const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
+    int KP, int CAP, u64 *__restrict__ out_keys, int *__restrict__ out_cnt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   u64 *list = reinterpret_cast<u64 *>(smem);            // [32][CAP]
   float *tau_s = reinterpret_cast<float *>(list + 32 * CAP);  // [32]
@@ -144,7 +171,7 @@ __global__ __launch_bounds__(64) void knn_select_kernel(
       const int k = 8 * g + 4 * h + u;
       float val = 0.f;
       if (qvalid) {
-        if (k < d) val = -2.0f * x[q * d + k];
+        if (k < d) val = -2.0f * centred(x[q * d + k], mu[k]);
         else if (k == d) val = 1.f;
         else if (k == d + 1) val = norms[q];
       }
@@ -377,10 +404,10 @@ __global__ __launch_bounds__(FB_THREADS) void knn_exact_scan_kernel(
 // ---- host orchestration ----------------------------------------------------------------------
 template <int NG>
 static void launch_select(int64_t nwaves, size_t lds, const float4 *P, const float *norms, const float *x,
-                          int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self, int KP,
-                          int CAP, u64 *keys, int *cnts) {
-  hipLaunchKernelGGL(knn_select_kernel<NG>, dim3((unsigned)nwaves), dim3(64), lds, stream(), P, norms, x, N, d,
-                     NB, q_begin, n_q, include_self, KP, CAP, keys, cnts);
+                          const float *mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q,
+                          int include_self, int KP, int CAP, u64 *keys, int *cnts) {
+  hipLaunchKernelGGL(knn_select_kernel<NG>, dim3((unsigned)nwaves), dim3(64), lds, stream(), P, norms, x, mu, N,
+                     d, NB, q_begin, n_q, include_self, KP, CAP, keys, cnts);
 }
 
 struct DevBuf {
@@ -417,11 +444,13 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   const int CAP = KP + 64;
   const int64_t NB = ceil_div(N, 32);
 
-  DevBuf P, norms, maxn, keys, cnts, oidx, odist, nflag, flagged, bnd_d, bnd_i;
+  DevBuf P, norms, maxn, keys, cnts, oidx, odist, nflag, flagged, bnd_d, bnd_i, partial, mu;
   int rc;
   if ((rc = P.alloc(sizeof(float4) * (size_t)(NB * NG * 64)))) return rc;
   if ((rc = norms.alloc(sizeof(float) * (size_t)N))) return rc;
   if ((rc = maxn.alloc(16))) return rc;
+  if ((rc = partial.alloc(sizeof(double) * (size_t)MEAN_BLOCKS * (size_t)d))) return rc;
+  if ((rc = mu.alloc(sizeof(float) * (size_t)d))) return rc;
   if ((rc = keys.alloc(sizeof(u64) * (size_t)(n_q * KP)))) return rc;
   if ((rc = cnts.alloc(sizeof(int) * (size_t)n_q))) return rc;
   if ((rc = oidx.alloc(sizeof(int32_t) * (size_t)(n_q * k)))) return rc;
@@ -436,10 +465,15 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
 
   {
     ProfScope prof(CC_PROF_KNN_PACK, 0.0);
-    hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, stream(), d_x, N, d,
-                       norms.as<float>(), maxn.as<unsigned>());
+    const int mean_threads = (int)round_up(d, 64);
+    hipLaunchKernelGGL(knn_colsum_kernel, dim3(MEAN_BLOCKS), dim3(mean_threads), 0, stream(), d_x, N, d,
+                       partial.as<double>());
+    hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(mean_threads), 0, stream(), partial.as<double>(), N, d,
+                       mu.as<float>());
+    hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, stream(), d_x,
+                       mu.as<float>(), N, d, norms.as<float>(), maxn.as<unsigned>());
     hipLaunchKernelGGL(knn_pack_kernel, dim3((unsigned)ceil_div(NB * NG * 64, 256)), dim3(256), 0, stream(), d_x,
-                       norms.as<float>(), N, d, NG, NB, P.as<float4>());
+                       mu.as<float>(), norms.as<float>(), N, d, NG, NB, P.as<float4>());
     CC_HIP(hipGetLastError());
   }
   {
@@ -448,8 +482,8 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
     ProfScope prof(CC_PROF_KNN_SELECT, 2.0 * (double)n_q * (double)N * (double)d);
 #define CC_SEL(NGV)                                                                                         \
   case NGV:                                                                                                 \
-    launch_select<NGV>(nwaves, lds, P.as<float4>(), norms.as<float>(), d_x, N, d, NB, q_begin, n_q,         \
-                       include_self, KP, CAP, keys.as<u64>(), cnts.as<int>());                              \
+    launch_select<NGV>(nwaves, lds, P.as<float4>(), norms.as<float>(), d_x, mu.as<float>(), N, d, NB,       \
+                       q_begin, n_q, include_self, KP, CAP, keys.as<u64>(), cnts.as<int>());                \
     break;
     switch (NG) {
       CC_SEL(1) CC_SEL(2) CC_SEL(3) CC_SEL(5) CC_SEL(9) CC_SEL(17)
@@ -458,9 +492,11 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
 #undef CC_SEL
     CC_HIP(hipGetLastError());
   }
-  // fp32 error bound of stage 1: d+2 fma terms on |terms| summing to <= 2(‖q‖²+‖c‖²),
-  // plus the rounding of the two norms to fp32.
-  const double eps_coef = 4.0 * (double)(d + 4) * 5.9604644775390625e-08;
+  // fp32 error bound of stage 1 relative to (‖q−μ‖² + ‖c−μ‖²), u = 2^-24:
+  //   (2(d+2)+1)·u  d+2 fma terms on |terms| summing to <= 2(‖q‖²+‖c‖²), norms rounded to fp32
+  // + 4(1+3u)·u     rounding of the centred coordinates fl(x−μ)
+  // < (2d+10)·u; twice that is used.
+  const double eps_coef = (4.0 * (double)(d + 4) + 8.0) * 5.9604644775390625e-08;
   {
     const size_t per_wave = (sizeof(double) * (size_t)(d + KP) + sizeof(int) * (size_t)KP + 15) / 16 * 16;
     ProfScope prof(CC_PROF_KNN_RERANK, 3.0 * (double)n_q * (double)KP * (double)d);

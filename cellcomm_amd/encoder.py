@@ -91,7 +91,7 @@ class HipEncoder:
         for i in range(lib.cc_encoder_num_weights(self._h)):
             r, c = ctypes.c_int64(), ctypes.c_int64()
             _lib.check(lib.cc_encoder_weight_shape(self._h, i, ctypes.byref(r), ctypes.byref(c)))
-            self._shapes.append((r.value, c.value) if c.value else (r.value,))
+            self._shapes.append((r.value, c.value) if c.value >= 0 else (r.value,))
         self._weights = None
         self.layers = [Layer(self, *spec) for spec in _layer_plan(arch, self.encoding_size, self.gene_size)]
         self.set_weights(self._initial_weights(seed))
@@ -135,7 +135,7 @@ class HipEncoder:
         lib = _lib.lib()
         for i, a in enumerate(arrs):
             rows = a.shape[0]
-            cols = a.shape[1] if a.ndim == 2 else 0
+            cols = a.shape[1] if a.ndim == 2 else -1
             _lib.check(lib.cc_encoder_set_weights(self._h, i, a.ctypes.data, rows, cols))
         self._weights = arrs
 

@@ -59,7 +59,8 @@ int cc_synchronize(void);
 int cc_encoder_create(int arch, int G, int E, int dtype, void **enc);
 void cc_encoder_free(void *enc);
 /* Number of weight arrays in Keras get_weights() order (14 cont, 8 cls) and
- * the expected shape of array `idx` (cols == 0 for a vector). */
+ * the expected shape of array `idx` (cols == -1 for a vector; a kernel may
+ * legitimately be [rows x 0] when int(G*0.1) == 0). */
 int cc_encoder_num_weights(void *enc);
 int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols);
 /* Upload array `idx` (Keras order: kernels are [in x out] row-major, y = x@K+b;
