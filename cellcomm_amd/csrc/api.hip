@@ -85,7 +85,7 @@ struct Encoder {
   int64_t *d_row_ids = nullptr;
 };
 
-static int64_t pad32(int64_t v) { return v == 0 ? 32 : round_up(v, GEMM_BK); }
+static int64_t pad32(int64_t v) { return v == 0 ? GEMM_BK : round_up(v, GEMM_BK); }  // pad to the GEMM K-step
 
 static void encoder_shapes(Encoder *e) {
   const int64_t G = e->G, E = e->E;
@@ -170,7 +170,7 @@ static int encoder_ensure_ws(Encoder *e, int64_t rows) {
   e->ldx = pad32(e->G);
   e->ld1 = pad32(e->w0);
   e->ld2 = pad32(e->w1);
-  e->ld3 = 160;
+  e->ld3 = pad32(150);
   int rc;
   if ((rc = alloc_zero(&e->x, rows, e->ldx))) return rc;
   if ((rc = alloc_zero(&e->h1, rows, e->ld1))) return rc;

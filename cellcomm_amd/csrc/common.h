@@ -54,7 +54,10 @@ int launch_gather(const int64_t *d_indptr, const int32_t *d_indices, const float
                   float *d_out, double avg_nnz_hint);
 
 // gemm.hip
-constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = 32;
+#ifndef CC_GEMM_BK
+#define CC_GEMM_BK 32
+#endif
+constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = CC_GEMM_BK;
 enum Act { ACT_SIGMOID = 0, ACT_LINEAR = 1 };
 struct PackedWeight {
   float *d_w = nullptr;     // [NT][KT][BK/4][BN][4]

@@ -35,22 +35,49 @@
 namespace cc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+// native vector (not HIP's float4 struct): arrays of it stay in registers after unrolling
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// Tuned on MI355X (tools/gemm_sweep.sh): 3 workgroups per CU (<=168 VGPRs) and a raised
+// priority over the MFMA cluster gave 127 -> 136 TFLOP/s on layer 1.
+#ifndef CC_GEMM_MINWAVES
+#define CC_GEMM_MINWAVES 3
+#endif
+#ifndef CC_GEMM_SETPRIO
+#define CC_GEMM_SETPRIO 1
+#endif
 
 constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
-constexpr int LDS_A_STRIDE = BK + 4;           // floats
+constexpr int LDS_A_STRIDE = BK + 4;            // floats; (BK+4)·r mod 64 distinct for r mod 16
 constexpr int GEMM_THREADS = 256;
-constexpr int TILE_W_FLOAT4 = (BK / 4) * BN;   // 1024 float4 = 16 KiB
-constexpr int GROUP_M = 8;
+constexpr int TILE_W_FLOAT4 = (BK / 4) * BN;    // float4 per packed W tile
+constexpr int A_F4_PER_ROW = BK / 4;            // float4 per A-tile row
+constexpr int A_ROWS_PER_PASS = GEMM_THREADS / A_F4_PER_ROW;
+constexpr int NA = BM / A_ROWS_PER_PASS;        // A float4 staged per thread
+constexpr int NB = TILE_W_FLOAT4 / GEMM_THREADS;  // W float4 staged per thread
+#ifndef CC_GEMM_GROUP_M
+#define CC_GEMM_GROUP_M 8
+#endif
+constexpr int GROUP_M = CC_GEMM_GROUP_M;
+static_assert(BN == 128 && (BK == 32 || BK == 64), "tile shape");
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
-__global__ __launch_bounds__(GEMM_THREADS) void gemm_bias_act_kernel(
-    const float *__restrict__ A1, int64_t lda1, const float *__restrict__ A2, int64_t lda2,
-    int64_t M, const float4 *__restrict__ Wp, const float *__restrict__ bias, int KT1, int KT,
-    int N, int MT, int NT, float *__restrict__ C, int64_t ldc, int act) {
+// KCLASS only names the instantiation (so profilers tell layer 1 / layer 2 / tail apart).
+template <int KCLASS>
+__global__
+#if CC_GEMM_MINWAVES > 0
+__launch_bounds__(GEMM_THREADS, CC_GEMM_MINWAVES)
+#else
+__launch_bounds__(GEMM_THREADS)
+#endif
+void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const float *__restrict__ A2,
+                          int64_t lda2, int64_t M, const f32x4 *__restrict__ Wp,
+                          const float *__restrict__ bias, int KT1, int KT, int N, int MT, int NT,
+                          float *__restrict__ C, int64_t ldc, int act) {
   __shared__ __attribute__((aligned(16))) float lds[BM * LDS_A_STRIDE + TILE_W_FLOAT4 * 4];
   float *As = lds;
-  float4 *Bs4 = reinterpret_cast<float4 *>(lds + BM * LDS_A_STRIDE);
+  f32x4 *Bs4 = reinterpret_cast<f32x4 *>(lds + BM * LDS_A_STRIDE);
 
   // ---- workgroup → tile ---------------------------------------------------
   const int nwg = MT * NT;
@@ -70,54 +97,29 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bias_act_kernel(
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
 
-  // ---- staging addresses (32-bit per-thread offsets from a scalar tile base) ----
-  const int a_row = tid >> 3;  // + 32 p
-  const int a_k4 = tid & 7;
-  int a_off1[4], a_off2[4];
+  // ---- staging: per-thread running pointers into A (re-based once at the
+  //      segment switch) and a scalar running pointer into the packed W tiles ----
+  const int a_row = tid / A_F4_PER_ROW;  // + A_ROWS_PER_PASS · p
+  const int a_k4 = tid % A_F4_PER_ROW;
+  int a_lr[NA];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
-    int64_t gr = m0 + a_row + 32 * p;
-    const int lr = (int)((gr < M ? gr : M - 1) - m0);  // clamp the M tail onto a valid row
-    a_off1[p] = lr * (int)lda1 + 4 * a_k4;
-    a_off2[p] = lr * (int)lda2 + 4 * a_k4;
+  for (int p = 0; p < NA; ++p) {
+    const int64_t gr = m0 + a_row + A_ROWS_PER_PASS * p;
+    a_lr[p] = (int)((gr < M ? gr : M - 1) - m0);  // clamp the M tail onto a valid row
   }
-  const float *A1t = A1 + m0 * lda1;
-  const float *A2t = A2 + m0 * lda2;
-  const float4 *Wtile = Wp + (int64_t)n_tile * KT * TILE_W_FLOAT4 + tid;
+  const float *pa[NA];
+  {
+    const float *base = KT1 > 0 ? A1 + m0 * lda1 : A2 + m0 * lda2;
+    const int lda = (int)(KT1 > 0 ? lda1 : lda2);
+#pragma unroll
+    for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * lda + 4 * a_k4;
+  }
+  const f32x4 *wt = Wp + (int64_t)n_tile * KT * TILE_W_FLOAT4 + tid;
 
-  float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
-  // Global → registers for K-step kt.  No lambdas / no conditionals around the
-  // loads: the eight staging registers must stay in VGPRs (not scratch) so that
-  // the loads stay in flight behind the MFMAs of the current K-step.
-#define CC_STAGE_LOAD(kt_)                                                            \
-  {                                                                                   \
-    const int kt__ = (kt_);                                                           \
-    const bool seg1 = kt__ < KT1;                                                     \
-    const float *At = seg1 ? A1t + (int64_t)kt__ * BK : A2t + (int64_t)(kt__ - KT1) * BK; \
-    const int o0 = seg1 ? a_off1[0] : a_off2[0], o1 = seg1 ? a_off1[1] : a_off2[1];   \
-    const int o2 = seg1 ? a_off1[2] : a_off2[2], o3 = seg1 ? a_off1[3] : a_off2[3];   \
-    ra0 = *reinterpret_cast<const float4 *>(At + o0);                                 \
-    ra1 = *reinterpret_cast<const float4 *>(At + o1);                                 \
-    ra2 = *reinterpret_cast<const float4 *>(At + o2);                                 \
-    ra3 = *reinterpret_cast<const float4 *>(At + o3);                                 \
-    const float4 *wt = Wtile + (int64_t)kt__ * TILE_W_FLOAT4;                         \
-    rb0 = wt[0];                                                                      \
-    rb1 = wt[GEMM_THREADS];                                                           \
-    rb2 = wt[2 * GEMM_THREADS];                                                       \
-    rb3 = wt[3 * GEMM_THREADS];                                                       \
-  }
-#define CC_STAGE_WRITE()                                                              \
-  {                                                                                   \
-    float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;                                 \
-    *reinterpret_cast<float4 *>(aw) = ra0;                                            \
-    *reinterpret_cast<float4 *>(aw + 32 * LDS_A_STRIDE) = ra1;                        \
-    *reinterpret_cast<float4 *>(aw + 64 * LDS_A_STRIDE) = ra2;                        \
-    *reinterpret_cast<float4 *>(aw + 96 * LDS_A_STRIDE) = ra3;                        \
-    Bs4[tid] = rb0;                                                                   \
-    Bs4[tid + GEMM_THREADS] = rb1;                                                    \
-    Bs4[tid + 2 * GEMM_THREADS] = rb2;                                                \
-    Bs4[tid + 3 * GEMM_THREADS] = rb3;                                                \
-  }
+  // The staging registers must stay in VGPRs (hipcc demotes them to scratch when
+  // they are touched through lambdas or selected between arrays) so that the
+  // loads stay in flight behind the MFMAs of the current K-step.
+  f32x4 ra[NA], rb[NB];
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -128,42 +130,69 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bias_act_kernel(
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   if (KT > 0) {
-    CC_STAGE_LOAD(0);
-    CC_STAGE_WRITE();
+#pragma unroll
+    for (int p = 0; p < NA; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
+#pragma unroll
+    for (int p = 0; p < NB; ++p) rb[p] = wt[p * GEMM_THREADS];
+    wt += TILE_W_FLOAT4;
+    float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;
+#pragma unroll
+    for (int p = 0; p < NA; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
+#pragma unroll
+    for (int p = 0; p < NB; ++p) Bs4[tid + p * GEMM_THREADS] = rb[p];
   }
   __syncthreads();
 
   const float *a_lds = As + (wm * 64 + r) * LDS_A_STRIDE + 4 * h;
-  const float4 *b_lds = Bs4 + h * BN + wn * 64 + r;
+  const f32x4 *b_lds = Bs4 + h * BN + wn * 64 + r;
 
   for (int kt = 0; kt < KT; ++kt) {
-    // prefetch K-step kt+1 (the last step re-reads its own tile: branch-free)
-    CC_STAGE_LOAD(kt + 1 < KT ? kt + 1 : kt);
+    const bool more = kt + 1 < KT;  // wave-uniform
+    if (more) {
+      if (kt + 1 == KT1) {  // first tile of segment 2: re-base the A pointers (once per kernel)
+        const float *base = A2 + m0 * lda2;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * (int)lda2 + 4 * a_k4;
+      }
+#pragma unroll
+      for (int p = 0; p < NA; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
+#pragma unroll
+      for (int p = 0; p < NB; ++p) rb[p] = wt[p * GEMM_THREADS];
+      wt += TILE_W_FLOAT4;
+    }
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
+#if CC_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int t = 0; t < BK / 8; ++t) {
-      float4 a[2], b[2];
+      f32x4 a[2], b[2];
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
-        a[mt] = *reinterpret_cast<const float4 *>(a_lds + mt * 32 * LDS_A_STRIDE + 8 * t);
+        a[mt] = *reinterpret_cast<const f32x4 *>(a_lds + mt * 32 * LDS_A_STRIDE + 8 * t);
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) b[nt] = b_lds[2 * t * BN + nt * 32];
-      const float av[2][4] = {{a[0].x, a[0].y, a[0].z, a[0].w}, {a[1].x, a[1].y, a[1].z, a[1].w}};
-      const float bv[2][4] = {{b[0].x, b[0].y, b[0].z, b[0].w}, {b[1].x, b[1].y, b[1].z, b[1].w}};
 #pragma unroll
       for (int u = 0; u < 4; ++u)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt][u], bv[nt][u], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][u], b[nt][u], acc[mt][nt], 0, 0, 0);
+    }
+#if CC_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    __syncthreads();
+    if (more) {
+      float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;
+#pragma unroll
+      for (int p = 0; p < NA; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
+#pragma unroll
+      for (int p = 0; p < NB; ++p) Bs4[tid + p * GEMM_THREADS] = rb[p];
     }
     __syncthreads();
-    CC_STAGE_WRITE();
-    __syncthreads();
   }
-#undef CC_STAGE_LOAD
-#undef CC_STAGE_WRITE
 
   // ---- epilogue: bias + activation, 128-byte row segments per half-wave ------
 #pragma unroll
@@ -190,13 +219,15 @@ __global__ __launch_bounds__(GEMM_THREADS) void gemm_bias_act_kernel(
 // n = n_tile·128 + i.
 __global__ void pack_weight_kernel(const float *__restrict__ w, int64_t K1, int64_t K2, int64_t N,
                                    int64_t KT1, int64_t KT, int64_t NT, float *__restrict__ dst) {
-  const int64_t total = NT * KT * (int64_t)TILE_W_FLOAT4 * 4;
+  constexpr int TILE_FLOATS = TILE_W_FLOAT4 * 4;
+  const int64_t total = NT * KT * (int64_t)TILE_FLOATS;
   for (int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; f < total;
        f += (int64_t)gridDim.x * blockDim.x) {
-    const int c = f & 3;
-    const int i = (f >> 2) & (BN - 1);
-    const int j = (f >> 9) & (BK / 4 - 1);
-    const int64_t tile = f >> 12;  // 4096 floats per tile
+    const int within = (int)(f % TILE_FLOATS);
+    const int c = within & 3;
+    const int i = (within >> 2) & (BN - 1);
+    const int j = within / (4 * BN);
+    const int64_t tile = f / TILE_FLOATS;
     const int64_t kt = tile % KT, nt = tile / KT;
     const int64_t n = nt * BN + i;
     int64_t src_row;
@@ -220,7 +251,6 @@ void free_weight(PackedWeight *w) {
 
 int pack_weight(const float *w, const float *bias, int64_t K1, int64_t K2, int64_t N,
                 PackedWeight *out) {
-  static_assert(BN == 128 && BK == 32, "pack index math assumes 128 x 32 tiles");
   free_weight(out);
   out->K1 = K1; out->K2 = K2; out->N = N;
   out->KT1 = ceil_div(K1, BK); out->KT2 = ceil_div(K2, BK);
@@ -257,13 +287,19 @@ int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, in
              "gemm: segment 1 needs lda >= %lld (got %lld)", (long long)(W.KT1 * BK), (long long)lda1);
   CC_REQUIRE(W.KT2 == 0 || (A2 && lda2 >= W.KT2 * BK && lda2 % 4 == 0),
              "gemm: segment 2 needs lda >= %lld (got %lld)", (long long)(W.KT2 * BK), (long long)lda2);
+  CC_REQUIRE(lda1 * BM < (int64_t)2147483647 && lda2 * BM < (int64_t)2147483647, "gemm: lda too large");
   const int64_t MT = ceil_div(M, BM);
   const int64_t nwg = MT * W.NT;
   CC_REQUIRE(nwg < (int64_t)2147483647, "gemm: grid too large");
   ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
-  hipLaunchKernelGGL(gemm_bias_act_kernel, dim3((unsigned)nwg), dim3(GEMM_THREADS), 0, stream(), A1, lda1, A2,
-                     lda2, M, reinterpret_cast<const float4 *>(W.d_w), W.d_bias, (int)W.KT1,
-                     (int)(W.KT1 + W.KT2), (int)W.N, (int)MT, (int)W.NT, C, ldc, act);
+#define CC_LAUNCH_GEMM(KC)                                                                                  \
+  hipLaunchKernelGGL(gemm_bias_act_kernel<KC>, dim3((unsigned)nwg), dim3(GEMM_THREADS), 0, stream(), A1,    \
+                     lda1, A2, lda2, M, reinterpret_cast<const f32x4 *>(W.d_w), W.d_bias, (int)W.KT1,     \
+                     (int)(W.KT1 + W.KT2), (int)W.N, (int)MT, (int)W.NT, C, ldc, act)
+  if (prof_class == CC_PROF_GEMM_L1) CC_LAUNCH_GEMM(1);
+  else if (prof_class == CC_PROF_GEMM_L2) CC_LAUNCH_GEMM(2);
+  else CC_LAUNCH_GEMM(3);
+#undef CC_LAUNCH_GEMM
   CC_HIP(hipGetLastError());
   return CC_OK;
 }
