@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--arch', default='cont')
     ap.add_argument('--batch-rows', type=int, default=0, help='rows per pass through the layer stack (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-profile', action='store_true', help='diagnostic: no HIP events in the timed region')
     ap.add_argument('--cpu-sample-cells', type=int, default=2048)
     ap.add_argument('--cpu-sample-knn', type=int, default=20000)
     return ap.parse_args()
@@ -111,12 +112,13 @@ def main():
     enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321,
                         batch_rows=args.batch_rows or None)
     backend = pipeline.HipBackend()
-    host_enc = np.empty((hi - lo, args.latent), dtype=np.float32)
+    host_enc_t = torch.empty((hi - lo, args.latent), dtype=torch.float32, pin_memory=True)
+    host_enc = host_enc_t.numpy()
 
     def step():
         res = pipeline.encode_and_knn(enc, local, args.k, backend=backend)
         q0 = res['q_begin']
-        host_enc[:] = res['encodings'][q0:q0 + (hi - lo)].cpu().numpy()
+        host_enc_t.copy_(res['encodings'][q0:q0 + (hi - lo)])      # D2H into pinned memory
         return res
 
     def fence():
@@ -127,7 +129,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    _lib.profile_enable(True)
+    _lib.profile_enable(not args.no_profile)
     _lib.profile_reset()
     fence()
     t0 = time.perf_counter()

@@ -29,9 +29,24 @@ static std::vector<ProfRec> g_pending;
 static int64_t g_launches[CC_PROF_NUM];
 static double g_ms[CC_PROF_NUM], g_work[CC_PROF_NUM];
 
+// events are recycled: creating/destroying ~170 of them per 100k-cell pass is measurable
+static std::vector<hipEvent_t> g_event_pool;
+static hipEvent_t event_get() {
+  if (!g_event_pool.empty()) {
+    hipEvent_t e = g_event_pool.back();
+    g_event_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) return nullptr;
+  return e;
+}
+
 ProfScope::ProfScope(int klass_, double work_) : klass(klass_), work(work_) {
   if (!g_prof_on) return;
-  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { e0 = e1 = nullptr; return; }
+  e0 = event_get();
+  e1 = event_get();
+  if (!e0 || !e1) { e0 = e1 = nullptr; return; }
   (void)hipEventRecord(e0, g_stream);
 }
 ProfScope::~ProfScope() {
@@ -49,8 +64,8 @@ static void prof_drain() {
       g_ms[r.klass] += ms;
       g_work[r.klass] += r.work;
     }
-    (void)hipEventDestroy(r.e0);
-    (void)hipEventDestroy(r.e1);
+    g_event_pool.push_back(r.e0);
+    g_event_pool.push_back(r.e1);
   }
   g_pending.clear();
 }
@@ -60,10 +75,20 @@ struct Csr {
   int64_t *indptr = nullptr;
   int32_t *indices = nullptr;
   float *vals = nullptr;
+  int32_t *chunk_rel = nullptr;  // per-row non-zero offsets at every 4096-column boundary (gather.hip)
   int64_t n_rows = 0, nnz = 0;
   int G = 0;
   bool owned = false;
 };
+
+static int csr_build_index(Csr *c) {
+  const size_t count = (size_t)c->n_rows * (size_t)gather_chunk_count(c->G);
+  CC_HIP(hipMalloc(&c->chunk_rel, sizeof(int32_t) * (count ? count : 1)));
+  int rc = build_chunk_index(c->indptr, c->indices, c->n_rows, c->G, c->chunk_rel);
+  if (rc) return rc;
+  CC_HIP(hipStreamSynchronize(stream()));
+  return CC_OK;
+}
 
 // ---- encoder handle ----------------------------------------------------------------
 struct WShape { int64_t rows, cols; };
@@ -234,7 +259,7 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
       CC_HIP(hipMemcpyAsync(e->d_row_ids, row_ids + off, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, stream()));
       d_ids = e->d_row_ids;
     }
-    if ((rc = launch_gather(c->indptr, c->indices, c->vals, d_ids, row_start + off, m, e->G, e->ldx, e->x,
+    if ((rc = launch_gather(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start + off, m, e->G, e->ldx, e->x,
                             nnz_per_row * (double)m)))
       return rc;
     if ((rc = encoder_forward(e, m, dev_out + off * e->E))) return rc;
@@ -369,6 +394,7 @@ int cc_csr_upload(const int64_t *indptr, const int32_t *indices, const float *va
     set_error("hipMemcpy failed for CSR upload");
     return fail(CC_EHIP);
   }
+  if (int rc = csr_build_index(c)) return fail(rc);
   *csr = c;
   return CC_OK;
 }
@@ -382,6 +408,7 @@ int cc_csr_wrap_device(const int64_t *dev_indptr, const int32_t *dev_indices, co
   c->indices = const_cast<int32_t *>(dev_indices);
   c->vals = const_cast<float *>(dev_vals);
   c->n_rows = n_rows; c->nnz = nnz; c->G = G; c->owned = false;
+  if (int rc = csr_build_index(c)) { cc_csr_free(c); return rc; }
   *csr = c;
   return CC_OK;
 }
@@ -389,6 +416,7 @@ int cc_csr_wrap_device(const int64_t *dev_indptr, const int32_t *dev_indices, co
 void cc_csr_free(void *csr) {
   if (!csr) return;
   Csr *c = static_cast<Csr *>(csr);
+  if (c->chunk_rel) (void)hipFree(c->chunk_rel);
   if (c->owned) {
     if (c->indptr) (void)hipFree(c->indptr);
     if (c->indices) (void)hipFree(c->indices);
@@ -413,7 +441,7 @@ int cc_gather_dense(void *csr, const int64_t *row_ids, int64_t row_start, int64_
   }
   if (!out_is_device) CC_HIP(hipMalloc(&d_out, sizeof(float) * (size_t)(n * ld)));
   const double nnz_hint = c->n_rows ? (double)c->nnz / (double)c->n_rows * (double)n : 0.0;
-  rc = launch_gather(c->indptr, c->indices, c->vals, d_ids, row_start, n, c->G, ld, d_out, nnz_hint);
+  rc = launch_gather(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start, n, c->G, ld, d_out, nnz_hint);
   if (rc == CC_OK && !out_is_device) {
     if (hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)(n * ld), hipMemcpyDeviceToHost, stream()) != hipSuccess) {
       set_error("hipMemcpy D2H failed in cc_gather_dense");

@@ -49,9 +49,12 @@ static inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
 // ---- kernels' host launchers (defined in the .hip files) -------------------
 
 // gather.hip
+int gather_chunk_count(int G);  // entries per row of the chunk index
+int build_chunk_index(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, int G,
+                      int32_t *d_chunk_rel);
 int launch_gather(const int64_t *d_indptr, const int32_t *d_indices, const float *d_vals,
-                  const int64_t *d_row_ids, int64_t row_start, int64_t n, int G, int64_t ld,
-                  float *d_out, double avg_nnz_hint);
+                  const int32_t *d_chunk_rel, const int64_t *d_row_ids, int64_t row_start, int64_t n, int G,
+                  int64_t ld, float *d_out, double nnz_hint);
 
 // gemm.hip
 #ifndef CC_GEMM_BK

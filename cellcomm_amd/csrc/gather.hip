@@ -7,12 +7,15 @@
 //
 // One 256-thread workgroup owns one (row, 4096-column chunk).  The chunk is
 // staged in LDS: zero-filled with 16-byte LDS stores, the row's non-zeros that
-// fall in the chunk (found by two binary searches on the row's sorted column
-// ids) are scattered into it with 4-byte LDS stores, and the chunk then leaves
-// as full, coalesced 16-byte-per-lane global stores.  HBM therefore sees one
-// streaming read of (index, value) pairs and one streaming write of the dense
-// tile; nothing is read-modify-written.  16 KiB of LDS per workgroup keeps
-// 8 workgroups (32 waves) resident per CU.
+// fall in the chunk are scattered into it with 4-byte LDS stores, and the chunk
+// then leaves as full, coalesced 16-byte-per-lane global stores.  Where a row's
+// non-zeros cross each 4096-column boundary is precomputed once per matrix
+// (csr_chunk_index_kernel): a binary search per workgroup put ~22 dependent
+// global-load round trips in front of every 16 KiB of stores (3.0 TB/s); with
+// the index the dependent chain is indptr/index -> (col, val) -> LDS -> store.
+// HBM sees one streaming read of (index, value) pairs and one streaming write of
+// the dense tile; nothing is read-modify-written.  16 KiB of LDS per workgroup
+// keeps 8 workgroups (32 waves) resident per CU.
 //
 // Algorithmic bytes per cell: 8·nnz + 8 (CSR read) + 4·ld (dense write).
 #include "common.h"
@@ -31,10 +34,22 @@ __device__ __forceinline__ int64_t lower_bound_i32(const int32_t *__restrict__ a
   return lo;
 }
 
+// chunk_rel[row·(NC+1) + j] = number of non-zeros of `row` with column < j·4096
+__global__ void csr_chunk_index_kernel(const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+                                       int64_t n_rows, int nc1, int32_t *__restrict__ chunk_rel) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_rows * nc1) return;
+  const int64_t row = t / nc1;
+  const int j = (int)(t % nc1);
+  const int64_t beg = indptr[row], end = indptr[row + 1];
+  chunk_rel[t] = (int32_t)(lower_bound_i32(indices, beg, end, j * GATHER_CH) - beg);
+}
+
 __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
-    const float *__restrict__ vals, const int64_t *__restrict__ row_ids, int64_t row_start,
-    int nchunks, int64_t ld, float *__restrict__ out) {
+    const float *__restrict__ vals, const int32_t *__restrict__ chunk_rel, int nc1,
+    const int64_t *__restrict__ row_ids, int64_t row_start, int nchunks, int64_t ld,
+    float *__restrict__ out) {
   __shared__ __attribute__((aligned(16))) float tile[GATHER_CH];
   const int tid = threadIdx.x;
   const int64_t r = blockIdx.x / nchunks;
@@ -42,15 +57,17 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_kernel(
   const int64_t row = row_ids ? row_ids[r] : row_start + r;
   const int64_t c0 = (int64_t)chunk * GATHER_CH;
   const int64_t c1 = (c0 + GATHER_CH < ld) ? c0 + GATHER_CH : ld;
-  const int64_t beg = indptr[row], end = indptr[row + 1];
+  const int64_t beg = indptr[row];
+  // chunks that lie wholly in the [G, ld) padding have no boundary of their own: clamp
+  const int32_t *rel = chunk_rel + row * nc1;
+  const int64_t lo = beg + rel[chunk < nc1 - 1 ? chunk : nc1 - 1];
+  const int64_t hi = beg + rel[chunk + 1 < nc1 - 1 ? chunk + 1 : nc1 - 1];
 
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
   float4 *tile4 = reinterpret_cast<float4 *>(tile);
 #pragma unroll
   for (int i = tid; i < GATHER_CH / 4; i += GATHER_THREADS) tile4[i] = z;
 
-  const int64_t lo = lower_bound_i32(indices, beg, end, (int32_t)c0);
-  const int64_t hi = lower_bound_i32(indices, lo, end, (int32_t)c1);
   __syncthreads();
   for (int64_t p = lo + tid; p < hi; p += GATHER_THREADS) tile[indices[p] - (int32_t)c0] = vals[p];
   __syncthreads();
@@ -61,18 +78,32 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_kernel(
   for (int i = tid; i < n4; i += GATHER_THREADS) orow[i] = tile4[i];
 }
 
+int gather_chunk_count(int G) { return (int)ceil_div(G, GATHER_CH) + 1; }
+
+int build_chunk_index(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, int G,
+                      int32_t *d_chunk_rel) {
+  const int nc1 = gather_chunk_count(G);
+  const int64_t total = n_rows * nc1;
+  if (total == 0) return CC_OK;
+  hipLaunchKernelGGL(csr_chunk_index_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
+                     d_indptr, d_indices, n_rows, nc1, d_chunk_rel);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
 int launch_gather(const int64_t *d_indptr, const int32_t *d_indices, const float *d_vals,
-                  const int64_t *d_row_ids, int64_t row_start, int64_t n, int G, int64_t ld,
-                  float *d_out, double nnz_hint) {
+                  const int32_t *d_chunk_rel, const int64_t *d_row_ids, int64_t row_start, int64_t n, int G,
+                  int64_t ld, float *d_out, double nnz_hint) {
   if (n == 0) return CC_OK;
   CC_REQUIRE(ld % 4 == 0 && ld >= G, "gather: ld=%lld must be a multiple of 4 and >= G=%d",
              (long long)ld, G);
   const int nchunks = (int)ceil_div(ld, GATHER_CH);
+  const int nc1 = gather_chunk_count(G);
   const int64_t nblocks = n * nchunks;
   CC_REQUIRE(nblocks < (int64_t)2147483647, "gather: grid too large (%lld blocks)", (long long)nblocks);
   ProfScope prof(CC_PROF_GATHER, 8.0 * nnz_hint + 8.0 * (double)n + 4.0 * (double)ld * (double)n);
   hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)nblocks), dim3(GATHER_THREADS), 0, stream(),
-                     d_indptr, d_indices, d_vals, d_row_ids, row_start, nchunks, ld, d_out);
+                     d_indptr, d_indices, d_vals, d_chunk_rel, nc1, d_row_ids, row_start, nchunks, ld, d_out);
   CC_HIP(hipGetLastError());
   return CC_OK;
 }

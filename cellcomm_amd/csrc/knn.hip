@@ -117,6 +117,9 @@ __global__ void knn_pack_kernel(const float *__restrict__ x, const float *__rest
 // ---- stage 1: select -------------------------------------------------------------
 constexpr int SEL_MAXJ = 4;  // list capacity <= 256 entries
 
+// Keep the KP smallest keys of list L[0..c) (sorted ascending) — rank by counting.  The
+// list is spread over the wave's registers and every key is broadcast with
+// v_readlane (scalar operand) instead of being re-read from LDS.
 __device__ __forceinline__ void compact_list(u64 *L, int *cnt_p, float *tau_p, int KP, int lane) {
   const int c = *cnt_p;
   u64 e[SEL_MAXJ];
@@ -127,11 +130,20 @@ __device__ __forceinline__ void compact_list(u64 *L, int *cnt_p, float *tau_p, i
     e[j] = (idx < c) ? L[idx] : ~0ull;
     rk[j] = 0;
   }
-  for (int i = 0; i < c; ++i) {
-    const u64 v = L[i];
 #pragma unroll
-    for (int j = 0; j < SEL_MAXJ; ++j)
-      if (64 * j < c) rk[j] += (v < e[j]) ? 1 : 0;
+  for (int j = 0; j < SEL_MAXJ; ++j) {
+    int cj = c - 64 * j;
+    if (cj > 0) {  // wave-uniform
+      cj = cj < 64 ? cj : 64;
+      const int lo = (int)(unsigned)(e[j] & 0xffffffffull), hi = (int)(unsigned)(e[j] >> 32);
+      for (int i = 0; i < cj; ++i) {
+        const u64 v = ((u64)(unsigned)__builtin_amdgcn_readlane(hi, i) << 32) |
+                      (u64)(unsigned)__builtin_amdgcn_readlane(lo, i);
+#pragma unroll
+        for (int jj = 0; jj < SEL_MAXJ; ++jj)
+          if (64 * jj < c) rk[jj] += (v < e[jj]) ? 1 : 0;
+      }
+    }
   }
   __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -146,14 +158,18 @@ __device__ __forceinline__ void compact_list(u64 *L, int *cnt_p, float *tau_p, i
   __builtin_amdgcn_wave_barrier();
 }
 
+// One wave owns 32 queries (MFMA columns) and their LDS lists exclusively, so appends
+// need no atomics: lanes r and r+32 (the two row-halves of query r) split the slots
+// [cnt, cnt + c0 + c1) by exchanging their pass counts.
 template <int NG>
 __global__ __launch_bounds__(64) void knn_select_kernel(
     const float4 *__restrict__ P, const float *__restrict__ norms, const float *__restrict__ x,
     const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
     int KP, int CAP, u64 *__restrict__ out_keys, int *__restrict__ out_cnt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  u64 *list = reinterpret_cast<u64 *>(smem);            // [32][CAP]
-  float *tau_s = reinterpret_cast<float *>(list + 32 * CAP);  // [32]
+  const int LS = CAP + 1;                               // odd stride: conflict-free 8-byte appends
+  u64 *list = reinterpret_cast<u64 *>(smem);            // [32][LS]
+  float *tau_s = reinterpret_cast<float *>(list + 32 * LS);  // [32]
   int *cnt = reinterpret_cast<int *>(tau_s + 32);       // [32]
 
   const int lane = threadIdx.x;
@@ -185,8 +201,20 @@ __global__ __launch_bounds__(64) void knn_select_kernel(
   }
   __builtin_amdgcn_wave_barrier();
   float tau = tau_s[r];
-  const int self = (include_self || !qvalid) ? -1 : (int)q;
   const int cap_guard = CAP - 32;
+  u64 *L = list + r * LS;
+
+  // accumulator register e of this lane is candidate row crow(e) = (e&3) + 8(e>>2) + 4h of the block
+  unsigned self_vm = 0xffffu, tail_vm = 0xffffu;  // bit e clear = candidate not admissible
+  int64_t self_blk = -1;
+  if (qvalid && !include_self) {
+    self_blk = q >> 5;
+    const int row = (int)(q & 31);
+    if (((row >> 2) & 1) == h) self_vm &= ~(1u << ((row & 3) | ((row >> 3) << 2)));
+  }
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
 
   float4 a[NG], an[NG];
 #pragma unroll
@@ -208,29 +236,38 @@ __global__ __launch_bounds__(64) void knn_select_kernel(
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, bq[g].z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, bq[g].w, acc, 0, 0, 0);
     }
-    bool any = false;
+    unsigned vm = (b == self_blk) ? self_vm : 0xffffu;
+    if (b == NB - 1) vm &= tail_vm;
+    int c_l = 0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) any |= (acc[e] <= tau);
-    if (__any(any)) {
-      const int cbase = (int)(b * 32) + 4 * h;
+    for (int e = 0; e < 16; ++e) c_l += (acc[e] <= tau && ((vm >> e) & 1u)) ? 1 : 0;
+    if (__any(c_l)) {
+      const int c_o = __shfl_xor(c_l, 32);
+      const int base = cnt[r];
+      int pos = base + (h ? c_o : 0);
+      const unsigned cbase = (unsigned)(b * 32) + 4 * h;
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        if (acc[e] <= tau) {
-          const int cand = cbase + (e & 3) + 8 * (e >> 2);
-          if (cand < N && cand != self) {
-            const int slot = atomicAdd(&cnt[r], 1);
-            list[r * CAP + slot] = ((u64)f32_to_ordered(acc[e]) << 32) | (unsigned)cand;
+        const bool pass = acc[e] <= tau && ((vm >> e) & 1u);
+        if (__ballot(pass)) {  // wave-uniform skip of registers nobody appends from
+          if (pass) {
+            L[pos] = ((u64)f32_to_ordered(acc[e]) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
+            ++pos;
           }
         }
       }
       __builtin_amdgcn_wave_barrier();
-      u64 need = __ballot(lane < 32 && cnt[r] > cap_guard);
-      while (need) {
-        const int qi = __builtin_ctzll(need);
-        need &= need - 1;
-        compact_list(list + qi * CAP, cnt + qi, tau_s + qi, KP, lane);
+      if (h == 0) cnt[r] = base + c_l + c_o;
+      __builtin_amdgcn_wave_barrier();
+      u64 need = __ballot(lane < 32 && base + c_l + c_o > cap_guard);
+      if (need) {
+        while (need) {
+          const int qi = __builtin_ctzll(need);
+          need &= need - 1;
+          compact_list(list + qi * LS, cnt + qi, tau_s + qi, KP, lane);
+        }
+        tau = tau_s[r];
       }
-      tau = tau_s[r];
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g) a[g] = an[g];
@@ -238,11 +275,11 @@ __global__ __launch_bounds__(64) void knn_select_kernel(
 
   // final: sort every list, emit the best KP keys per query
   for (int qi = 0; qi < 32; ++qi) {
-    compact_list(list + qi * CAP, cnt + qi, tau_s + qi, KP, lane);
+    compact_list(list + qi * LS, cnt + qi, tau_s + qi, KP, lane);
     const int64_t qo = (int64_t)blockIdx.x * 32 + qi;
     if (qo < n_q) {
       const int c = cnt[qi];
-      for (int i = lane; i < c; i += 64) out_keys[qo * KP + i] = list[qi * CAP + i];
+      for (int i = lane; i < c; i += 64) out_keys[qo * KP + i] = list[qi * LS + i];
       if (lane == 0) out_cnt[qo] = c;
     }
   }
@@ -410,11 +447,17 @@ static void launch_select(int64_t nwaves, size_t lds, const float4 *P, const flo
                      d, NB, q_begin, n_q, include_self, KP, CAP, keys, cnts);
 }
 
+// Grow-only device scratch kept across calls (hipMalloc/hipFree per call cost ~10 ms of the
+// 100k-cell step).  Never freed: the process owns one set.
 struct DevBuf {
   void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  size_t cap = 0;
   int alloc(size_t bytes) {
-    CC_HIP(hipMalloc(&p, bytes ? bytes : 16));
+    if (bytes <= cap && p) return CC_OK;
+    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+    bytes = bytes ? bytes : 16;
+    CC_HIP(hipMalloc(&p, bytes));
+    cap = bytes;
     return CC_OK;
   }
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
@@ -444,7 +487,7 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   const int CAP = KP + 64;
   const int64_t NB = ceil_div(N, 32);
 
-  DevBuf P, norms, maxn, keys, cnts, oidx, odist, nflag, flagged, bnd_d, bnd_i, partial, mu;
+  static DevBuf P, norms, maxn, keys, cnts, oidx, odist, nflag, flagged, bnd_d, bnd_i, partial, mu;
   int rc;
   if ((rc = P.alloc(sizeof(float4) * (size_t)(NB * NG * 64)))) return rc;
   if ((rc = norms.alloc(sizeof(float) * (size_t)N))) return rc;
@@ -478,7 +521,7 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   }
   {
     const int64_t nwaves = ceil_div(n_q, 32);
-    const size_t lds = sizeof(u64) * 32 * (size_t)CAP + 32 * 8;
+    const size_t lds = sizeof(u64) * 32 * (size_t)(CAP + 1) + 32 * 8;
     ProfScope prof(CC_PROF_KNN_SELECT, 2.0 * (double)n_q * (double)N * (double)d);
 #define CC_SEL(NGV)                                                                                         \
   case NGV:                                                                                                 \

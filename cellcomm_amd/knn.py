@@ -25,14 +25,21 @@ def knn_graph(encodings, k, include_self=False):
     return idx, dist
 
 
-def knn_graph_device(dev_ptr, n_total, d, k, q_begin=0, n_q=None, include_self=False):
+def knn_graph_device(dev_ptr, n_total, d, k, q_begin=0, n_q=None, include_self=False, out=None):
     """Same for encodings already in HBM (`dev_ptr` = device address of a
     contiguous float32 [n_total x d]); queries are rows [q_begin, q_begin+n_q) and
-    the returned indices are global row numbers."""
+    the returned indices are global row numbers.  `out=(idx, dist)` supplies the
+    host result arrays (e.g. views of pinned memory, which makes the copy-out DMA)."""
     lib = _lib.ensure_init()
     n_q = n_total - q_begin if n_q is None else n_q
-    idx = np.empty((n_q, k), dtype=np.int32)
-    dist = np.empty((n_q, k), dtype=np.float32)
+    if out is None:
+        idx = np.empty((n_q, k), dtype=np.int32)
+        dist = np.empty((n_q, k), dtype=np.float32)
+    else:
+        idx, dist = out
+        if idx.shape != (n_q, k) or dist.shape != (n_q, k) or idx.dtype != np.int32 or dist.dtype != np.float32 \
+                or not idx.flags.c_contiguous or not dist.flags.c_contiguous:
+            raise ValueError(f'out arrays must be C-contiguous int32/float32 of shape {(n_q, k)}')
     _lib.check(lib.cc_knn_l2_dev(dev_ptr, n_total, d, q_begin, n_q, int(k), int(bool(include_self)),
                                  idx.ctypes.data, dist.ctypes.data))
     return idx, dist

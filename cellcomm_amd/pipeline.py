@@ -28,6 +28,7 @@ class HipBackend:
         from . import _lib
         _lib.ensure_init()
         self.torch = torch
+        self._out_key, self._out = None, None
         torch.cuda.set_device(_lib._INIT_DEVICE)
 
     def alloc(self, rows, width):
@@ -41,7 +42,13 @@ class HipBackend:
     def knn(self, enc_all, n_total, q_begin, n_q, k, include_self):
         from .knn import knn_graph_device
         self.torch.cuda.synchronize()           # the all-gather ran on torch's stream
-        return knn_graph_device(enc_all.data_ptr(), n_total, enc_all.shape[1], k, q_begin, n_q, include_self)
+        key = (n_q, k)
+        if self._out_key != key:                # pinned host result buffers, reused across calls
+            self._out = (self.torch.empty(key, dtype=self.torch.int32, pin_memory=True),
+                         self.torch.empty(key, dtype=self.torch.float32, pin_memory=True))
+            self._out_key = key
+        out = (self._out[0].numpy(), self._out[1].numpy())
+        return knn_graph_device(enc_all.data_ptr(), n_total, enc_all.shape[1], k, q_begin, n_q, include_self, out=out)
 
 
 def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, group=None):
@@ -50,7 +57,8 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
     `local_matrix` holds the rows of this rank (block `shard_bounds(n_total, world,
     rank)` of the global matrix; the whole matrix when not distributed).
     Returns dict(encodings=[n_total x E] tensor on the backend device (all ranks),
-    idx=[n_local x k] int32 global neighbour ids, dist=[n_local x k] float32,
+    idx=[n_local x k] int32 global neighbour ids, dist=[n_local x k] float32 (with
+    HipBackend these are views of pinned buffers that the next call overwrites),
     q_begin=first global row of this rank, n_total=...).
     """
     backend = backend or HipBackend()
