@@ -145,6 +145,12 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
+        traffic = None   # HBM-side bytes per launch from the PMC passes committed under profiles/
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))['kernels']['cc::gemm_bias_act_kernel<1>']
+            traffic = (2 * pmc['FETCH_SIZE_KB']['mean_per_launch'] + pmc['WRITE_SIZE_KB']['mean_per_launch']) * 1024
+        except Exception:
+            pass
         g1 = prof['gemm_l1']
         avg_ms = g1['ms'] / max(g1['launches'], 1)
         flop_per_launch = g1['work'] / max(g1['launches'], 1)
@@ -165,7 +171,8 @@ def main():
                        'knn_fallback_queries_rank0': int(_lib.lib().cc_knn_last_fallback_count())},
             'roofline': {'kernel': 'gemm_bias_act_kernel (encoder layer 1, x[B x 30000] @ K1[30000 x 3000])',
                          'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_note': 'bytes per 8192-row launch, 2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/r01_pmc_hbm_traffic.json); algorithmic minimum 1.45e9',
                          'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch},
             'stages_rank0': stages,
         }
