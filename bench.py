@@ -92,6 +92,8 @@ def main():
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('CC_BENCH_ONE_DEVICE'):   # rehearsal: several ranks share GPU 0 (1-GPU box), gloo collective
+        local_rank = 0
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit(f'--gpus {args.gpus} needs one process per GPU: launch with '
@@ -100,7 +102,10 @@ def main():
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
+        if os.environ.get('CC_BENCH_ONE_DEVICE'):
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
 
     import cellcomm_amd as cc
     from cellcomm_amd import _lib, pipeline, synth
@@ -140,7 +145,7 @@ def main():
     prof = _lib.profile_snapshot()
     _lib.profile_enable(False)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+        t = torch.tensor([elapsed], dtype=torch.float64, device=backend.collective_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

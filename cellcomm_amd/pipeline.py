@@ -28,6 +28,12 @@ class HipBackend:
         from . import _lib
         _lib.ensure_init()
         self.torch = torch
+        # tensors handed to torch.distributed live on the GPU (RCCL); with a gloo group (CPU-only
+        # rehearsal of the multi-rank path on one GPU) they are staged through host memory
+        self.collective_device = 'cuda'
+        if torch.distributed.is_available() and torch.distributed.is_initialized() \
+                and torch.distributed.get_backend() == 'gloo':
+            self.collective_device = 'cpu'
         self._out_key, self._out = None, None
         torch.cuda.set_device(_lib._INIT_DEVICE)
 
@@ -75,8 +81,9 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
         return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=0, n_total=n_local)
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    counts = torch.zeros(world, dtype=torch.int64, device=backend.device)
-    mine = torch.tensor([n_local], dtype=torch.int64, device=backend.device)
+    cdev = getattr(backend, 'collective_device', backend.device)
+    counts = torch.zeros(world, dtype=torch.int64, device=cdev)
+    mine = torch.tensor([n_local], dtype=torch.int64, device=cdev)
     dist.all_gather_into_tensor(counts, mine, group=group)
     counts = counts.cpu().numpy()
     n_total = int(counts.sum())
@@ -91,7 +98,12 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
     gathered = backend.alloc(world * per, width)
     if backend.device == 'cuda':
         torch.cuda.synchronize()                # encoder ran on the library's stream
-    dist.all_gather_into_tensor(gathered, enc_local, group=group)      # the one collective
+    if cdev == backend.device:
+        dist.all_gather_into_tensor(gathered, enc_local, group=group)  # the one collective
+    else:
+        staged = torch.empty((world * per, width), dtype=torch.float32)
+        dist.all_gather_into_tensor(staged, enc_local.cpu(), group=group)
+        gathered.copy_(staged)
     if all(int(c) == per for c in counts[:-1]):
         enc_all = gathered[:n_total]            # blocks are already back to back
     else:
