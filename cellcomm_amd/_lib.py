@@ -50,6 +50,7 @@ SIGNATURES = {
     'cc_knn_l2': (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cc_knn_l2_dev': (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     'cc_knn_force_fallback': (c_int, [c_int]),
+    'cc_knn_force_full_select': (c_int, [c_int]),
     'cc_knn_last_fallback_count': (c_int64, []),
     'cc_profile_enable': (c_int, [c_int]),
     'cc_profile_reset': (c_int, []),

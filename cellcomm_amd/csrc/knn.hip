@@ -6,7 +6,7 @@
 // smallest (dist64(i,j), j), dist64 = sequential float64 sum of squared float64
 // differences; self excluded by index unless include_self.
 //
-// Three stages, bit-exact by construction:
+// Three stages, bit-exact by construction (stage 1 has two routes, see knn_run):
 //  1. select  — approximate distances ‖c‖² + ‖q‖² − 2 q·c for a 32-candidate x
 //     32-query tile come straight out of one chain of v_mfma_f32_32x32x2_f32
 //     (the norms ride along as two extra K rows), one wave per 32 queries.
@@ -19,6 +19,12 @@
 //     filters the accumulator registers; survivors are appended to a per-query
 //     LDS list with a wavefront-local atomic, and a list that could overflow is
 //     compacted by the wave (rank-by-counting on 64-bit (dist,idx) keys).
+//     Large inputs take the cheaper route 1b: `select` runs on a 1/8 sample of the
+//     candidate blocks only and yields a per-query threshold T (the m-th best of the
+//     sample, so that ~8m candidates lie below it); `collect` then streams ALL
+//     candidates through the same MFMA tiles and appends everything with approximate
+//     distance <= T to a per-query buffer — no lists, no compaction, and freely split
+//     over candidate ranges (one range per XCD keeps its panels in that XCD's L2).
 //  2. rerank  — the K' survivors are re-scored in float64 exactly as the oracle
 //     does and ordered by (dist64, idx).  The result is CERTIFIED when the k-th
 //     exact distance is below τ_approx(K') − ε, ε a rigorous bound on the fp32
@@ -30,9 +36,11 @@
 namespace cc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;  // native vector: arrays of it stay in VGPRs
 using u64 = unsigned long long;
 
 static bool g_force_fallback = false;
+static bool g_force_route_a = false;  // test hook: always take the full-select route
 static int64_t g_last_fallback = 0;
 
 __device__ __forceinline__ unsigned f32_to_ordered(float f) {
@@ -158,23 +166,117 @@ __device__ __forceinline__ void compact_list(u64 *L, int *cnt_p, float *tau_p, i
   __builtin_amdgcn_wave_barrier();
 }
 
+// Append the passing accumulator registers [E0, E1) of this lane to its query's list.
+template <int E0, int E1>
+__device__ __forceinline__ int append_regs(const f32x16 &acc, float tau, u64 *L, int pos, unsigned cbase) {
+#pragma unroll
+  for (int e = E0; e < E1; ++e) {
+    const bool pass = acc[e] <= tau;
+    if (__ballot(pass)) {  // wave-uniform skip of registers nobody appends from
+      if (pass) {
+        L[pos] = ((u64)f32_to_ordered(acc[e]) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
+        ++pos;
+      }
+    }
+  }
+  return pos;
+}
+template <int E0, int E1>
+__device__ __forceinline__ int count_regs(const f32x16 &acc, float tau) {
+  int c = 0;
+#pragma unroll
+  for (int e = E0; e < E1; ++e) c += (acc[e] <= tau) ? 1 : 0;
+  return c;
+}
+
 // One wave owns 32 queries (MFMA columns) and their LDS lists exclusively, so appends
 // need no atomics: lanes r and r+32 (the two row-halves of query r) split the slots
-// [cnt, cnt + c0 + c1) by exchanging their pass counts.
+// [cnt, cnt + c0 + c1) by exchanging their pass counts.  Lists hold CAP = K' + 16 keys
+// (12.5 KiB per wave at K' = 32 → 12 waves per CU, which is what covers the VALU
+// filter/compaction phases of one wave with the MFMAs of the others).  A step that
+// would overflow a list is replayed in two halves of 8 registers (≤ 16 appends per
+// query each), compacting to K' in front of each half.
 template <int NG>
-__global__ __launch_bounds__(64) void knn_select_kernel(
+__device__ __forceinline__ void select_step(const float4 (&a)[NG], const float4 (&bq)[NG], int64_t b, int64_t NB,
+                                            int64_t self_blk, int self_e, unsigned tail_vm, float &tau, u64 *list,
+                                            float *tau_s, int *cnt, int LS, int KP, int CAP, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, bq[g].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, bq[g].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, bq[g].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, bq[g].w, acc, 0, 0, 0);
+  }
+  // inadmissible candidates (the query itself, rows beyond N) become NaN: NaN <= tau is false
+  if (__any(b == self_blk) || b == NB - 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const bool kill = (b == self_blk && e == self_e) || (b == NB - 1 && !((tail_vm >> e) & 1u));
+      acc[e] = kill ? __builtin_nanf("") : acc[e];
+    }
+  }
+  int c_l = count_regs<0, 16>(acc, tau);
+  if (!__any(c_l)) return;
+  u64 *L = list + r * LS;
+  const unsigned cbase = (unsigned)(b * 32) + 4 * h;
+  int c_o = __shfl_xor(c_l, 32);
+  int base = cnt[r];
+  if (!__any(base + c_l + c_o > CAP)) {
+    append_regs<0, 16>(acc, tau, L, base + (h ? c_o : 0), cbase);
+    __builtin_amdgcn_wave_barrier();
+    if (h == 0) cnt[r] = base + c_l + c_o;
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
+  // careful path: two halves of 8 registers, room for 16 appends made in front of each
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    u64 need = __ballot(lane < 32 && cnt[r] > CAP - 16);
+    if (need) {
+      while (need) {
+        const int qi = __builtin_ctzll(need);
+        need &= need - 1;
+        compact_list(list + qi * LS, cnt + qi, tau_s + qi, KP, lane);
+      }
+      tau = tau_s[r];
+    }
+    c_l = half == 0 ? count_regs<0, 8>(acc, tau) : count_regs<8, 16>(acc, tau);
+    c_o = __shfl_xor(c_l, 32);
+    base = cnt[r];
+    if (half == 0) append_regs<0, 8>(acc, tau, L, base + (h ? c_o : 0), cbase);
+    else append_regs<8, 16>(acc, tau, L, base + (h ? c_o : 0), cbase);
+    __builtin_amdgcn_wave_barrier();
+    if (h == 0) cnt[r] = base + c_l + c_o;
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+template <int NG>
+__global__ __launch_bounds__(64, 3) void knn_select_kernel(
     const float4 *__restrict__ P, const float *__restrict__ norms, const float *__restrict__ x,
     const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
-    int KP, int CAP, u64 *__restrict__ out_keys, int *__restrict__ out_cnt) {
+    int KP, int CAP, int S, int64_t NBs, int bstride, u64 *__restrict__ out_keys, int *__restrict__ out_cnt) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int LS = CAP + 1;                               // odd stride: conflict-free 8-byte appends
   u64 *list = reinterpret_cast<u64 *>(smem);            // [32][LS]
   float *tau_s = reinterpret_cast<float *>(list + 32 * LS);  // [32]
   int *cnt = reinterpret_cast<int *>(tau_s + 32);       // [32]
 
+  // workgroup = (query tile, candidate split); split = blockIdx % S, so with S = 8 every XCD
+  // (round-robin dispatch) streams one eighth of the candidate panels out of its own L2
+  const int64_t tile = blockIdx.x / S;
+  const int split = blockIdx.x % S;
+  // this wave visits blocks b_lo, b_lo + bstride, ... < b_hi (bstride > 1: a sample of the blocks)
+  const int64_t b_lo = split * NBs;
+  const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
+
   const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t ql = (int64_t)blockIdx.x * 32 + r;
+  const int64_t ql = tile * 32 + r;
   const bool qvalid = ql < n_q;
   const int64_t q = q_begin + ql;
 
@@ -201,87 +303,325 @@ __global__ __launch_bounds__(64) void knn_select_kernel(
   }
   __builtin_amdgcn_wave_barrier();
   float tau = tau_s[r];
-  const int cap_guard = CAP - 32;
-  u64 *L = list + r * LS;
 
   // accumulator register e of this lane is candidate row crow(e) = (e&3) + 8(e>>2) + 4h of the block
-  unsigned self_vm = 0xffffu, tail_vm = 0xffffu;  // bit e clear = candidate not admissible
   int64_t self_blk = -1;
+  int self_e = -1;
   if (qvalid && !include_self) {
-    self_blk = q >> 5;
     const int row = (int)(q & 31);
-    if (((row >> 2) & 1) == h) self_vm &= ~(1u << ((row & 3) | ((row >> 3) << 2)));
+    if (((row >> 2) & 1) == h) {
+      self_blk = q >> 5;
+      self_e = (row & 3) | ((row >> 3) << 2);
+    }
   }
+  unsigned tail_vm = 0xffffu;  // bit e clear = row beyond N in the last block
 #pragma unroll
   for (int e = 0; e < 16; ++e)
     if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
 
-  float4 a[NG], an[NG];
+  // two register sets of candidate operands, ping-pong (no copies): block b+1 loads while b computes
+  float4 a0[NG], a1[NG];
 #pragma unroll
-  for (int g = 0; g < NG; ++g) a[g] = P[(int64_t)g * 64 + lane];
-
-  for (int64_t b = 0; b < NB; ++b) {
+  for (int g = 0; g < NG; ++g) a0[g] = P[(b_lo * NG + g) * 64 + lane];
+  for (int64_t b = b_lo; b < b_hi; b += 2 * bstride) {
+    const int64_t b1 = b + bstride, b2 = b + 2 * bstride;
     {
-      const int64_t bn = (b + 1 < NB) ? b + 1 : b;  // last step re-reads its own block
+      const int64_t bn = (b1 < b_hi) ? b1 : b;
 #pragma unroll
-      for (int g = 0; g < NG; ++g) an[g] = P[(bn * NG + g) * 64 + lane];
+      for (int g = 0; g < NG; ++g) a1[g] = P[(bn * NG + g) * 64 + lane];
     }
-    f32x16 acc;
+    select_step<NG>(a0, bq, b, NB, self_blk, self_e, tail_vm, tau, list, tau_s, cnt, LS, KP, CAP, lane);
+    if (b1 < b_hi) {
+      {
+        const int64_t bn = (b2 < b_hi) ? b2 : b1;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, bq[g].x, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, bq[g].y, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, bq[g].z, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, bq[g].w, acc, 0, 0, 0);
-    }
-    unsigned vm = (b == self_blk) ? self_vm : 0xffffu;
-    if (b == NB - 1) vm &= tail_vm;
-    int c_l = 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) c_l += (acc[e] <= tau && ((vm >> e) & 1u)) ? 1 : 0;
-    if (__any(c_l)) {
-      const int c_o = __shfl_xor(c_l, 32);
-      const int base = cnt[r];
-      int pos = base + (h ? c_o : 0);
-      const unsigned cbase = (unsigned)(b * 32) + 4 * h;
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const bool pass = acc[e] <= tau && ((vm >> e) & 1u);
-        if (__ballot(pass)) {  // wave-uniform skip of registers nobody appends from
-          if (pass) {
-            L[pos] = ((u64)f32_to_ordered(acc[e]) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
-            ++pos;
-          }
-        }
+        for (int g = 0; g < NG; ++g) a0[g] = P[(bn * NG + g) * 64 + lane];
       }
-      __builtin_amdgcn_wave_barrier();
-      if (h == 0) cnt[r] = base + c_l + c_o;
-      __builtin_amdgcn_wave_barrier();
-      u64 need = __ballot(lane < 32 && base + c_l + c_o > cap_guard);
-      if (need) {
-        while (need) {
-          const int qi = __builtin_ctzll(need);
-          need &= need - 1;
-          compact_list(list + qi * LS, cnt + qi, tau_s + qi, KP, lane);
-        }
-        tau = tau_s[r];
-      }
+      select_step<NG>(a1, bq, b1, NB, self_blk, self_e, tail_vm, tau, list, tau_s, cnt, LS, KP, CAP, lane);
     }
-#pragma unroll
-    for (int g = 0; g < NG; ++g) a[g] = an[g];
   }
 
   // final: sort every list, emit the best KP keys per query
   for (int qi = 0; qi < 32; ++qi) {
     compact_list(list + qi * LS, cnt + qi, tau_s + qi, KP, lane);
-    const int64_t qo = (int64_t)blockIdx.x * 32 + qi;
+    const int64_t qo = tile * 32 + qi;
     if (qo < n_q) {
       const int c = cnt[qi];
-      for (int i = lane; i < c; i += 64) out_keys[qo * KP + i] = list[qi * LS + i];
-      if (lane == 0) out_cnt[qo] = c;
+      const int64_t slot = qo * S + split;
+      for (int i = lane; i < c; i += 64) out_keys[slot * KP + i] = list[qi * LS + i];
+      if (lane == 0) out_cnt[slot] = c;
     }
+  }
+}
+
+// ---- stage 1b: collect everything below a fixed per-query threshold -----------------------
+// Same MFMA tile as select, but the threshold T[q] is fixed (from the sampled select), so there
+// is no list state.  Passing (approx, idx) keys are parked in a small per-wave LDS buffer
+// (positions from a wave prefix sum, no atomics) and flushed to buf[q][0..cap) through the
+// global per-query cursors 64 entries at a time — one atomic round trip per flush instead of
+// one per appending step.
+constexpr int COL_WB = 128;  // per-wave parking buffer entries
+
+struct WaveBuf {
+  u64 *key;    // [COL_WB]
+  int *qr;     // [COL_WB] query column 0..31
+  int n;       // entries parked (wave-uniform)
+};
+
+__device__ __forceinline__ void wavebuf_flush(WaveBuf &wb, u64 *__restrict__ buf, int *__restrict__ cursor,
+                                              int64_t q0, int64_t n_q, int cap, int lane) {
+  for (int i = lane; i < wb.n; i += 64) {
+    const int64_t ql = q0 + wb.qr[i];
+    if (ql < n_q) {
+      const int pos = atomicAdd(cursor + ql, 1);
+      if (pos < cap) buf[ql * cap + pos] = wb.key[i];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  wb.n = 0;
+}
+
+template <int NG>
+__device__ __forceinline__ void collect_step(const float4 (&a)[NG], const float4 (&bq)[NG], int64_t b, int64_t NB,
+                                             int64_t self_blk, int self_e, unsigned tail_vm, float T, WaveBuf &wb,
+                                             u64 *__restrict__ buf, int *__restrict__ cursor, int64_t q0,
+                                             int64_t n_q, int cap, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].x, bq[g].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].y, bq[g].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, bq[g].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, bq[g].w, acc, 0, 0, 0);
+  }
+  if (__any(b == self_blk) || b == NB - 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const bool kill = (b == self_blk && e == self_e) || (b == NB - 1 && !((tail_vm >> e) & 1u));
+      acc[e] = kill ? __builtin_nanf("") : acc[e];
+    }
+  }
+  const int c_l = count_regs<0, 16>(acc, T);
+  if (!__any(c_l)) return;
+  const unsigned cbase = (unsigned)(b * 32) + 4 * h;
+  // inclusive prefix sum of the per-lane pass counts over the wave
+  int incl = c_l;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  if (total > COL_WB) {
+    // pathological step (threshold admits > 128 of 1024 pairs): bypass the parking buffer
+    const int64_t ql = q0 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (acc[e] <= T && ql < n_q) {
+        const int pos = atomicAdd(cursor + ql, 1);
+        if (pos < cap) buf[ql * cap + pos] = ((u64)f32_to_ordered(acc[e]) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
+      }
+    }
+    return;
+  }
+  if (wb.n + total > COL_WB) wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
+  int pos = wb.n + incl - c_l;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const bool pass = acc[e] <= T;
+    if (__ballot(pass)) {
+      if (pass) {
+        wb.key[pos] = ((u64)f32_to_ordered(acc[e]) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
+        wb.qr[pos] = r;
+        ++pos;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  wb.n += total;
+}
+
+// Workgroup = 4 waves = 128 queries x one candidate split.  Candidate panels are staged through
+// LDS (4 blocks = 128 candidates per stage, double buffered, one barrier per stage) so that one
+// global read of a panel feeds all four waves: at one wave per panel read the kernel needs
+// 16 B/clk/CU of panel traffic and is fabric-bound once the candidate set outgrows the L2s.
+constexpr int COL_CB = 4;  // candidate blocks per LDS stage (COL_CB·64 = 256 float4 per group = one per thread)
+
+template <int NG>
+__global__ __launch_bounds__(256, 2) void knn_collect_kernel(
+    const float4 *__restrict__ P, const float *__restrict__ norms, const float *__restrict__ x,
+    const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
+    const float *__restrict__ T, int S, int64_t NBs, int cap, u64 *__restrict__ buf, int *__restrict__ cursor) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  float4 *stage = reinterpret_cast<float4 *>(smem);   // [2][COL_CB·NG·64], then the 4 parking buffers
+  constexpr int STAGE_F4 = COL_CB * NG * 64;
+
+  const int64_t tile = blockIdx.x / S;
+  const int split = blockIdx.x % S;
+  const int64_t b_lo = split * NBs;
+  const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t ql = tile * 128 + wave * 32 + r;
+  const bool qvalid = ql < n_q;
+  const int64_t q = q_begin + ql;
+
+  float4 bq[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    float v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int k = 8 * g + 4 * h + u;
+      float val = 0.f;
+      if (qvalid) {
+        if (k < d) val = -2.0f * centred(x[q * d + k], mu[k]);
+        else if (k == d) val = 1.f;
+        else if (k == d + 1) val = norms[q];
+      }
+      v[u] = val;
+    }
+    bq[g] = make_float4(v[0], v[1], v[2], v[3]);
+  }
+  const float Tq = qvalid ? T[ql] : -INFINITY;
+  const int64_t q0 = tile * 128 + wave * 32;   // first query of this wave
+  WaveBuf wb;
+  wb.key = reinterpret_cast<u64 *>(smem + sizeof(float4) * 2 * STAGE_F4) + wave * COL_WB;
+  wb.qr = reinterpret_cast<int *>(smem + sizeof(float4) * 2 * STAGE_F4 + sizeof(u64) * 4 * COL_WB) + wave * COL_WB;
+  wb.n = 0;
+
+  int64_t self_blk = -1;
+  int self_e = -1;
+  if (qvalid && !include_self) {
+    const int row = (int)(q & 31);
+    if (((row >> 2) & 1) == h) {
+      self_blk = q >> 5;
+      self_e = (row & 3) | ((row >> 3) << 2);
+    }
+  }
+  unsigned tail_vm = 0xffffu;
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
+
+  // stage s covers blocks b_lo + s·COL_CB .. +COL_CB-1 (clamped to the last block of the split:
+  // the clamped copies are loaded but never used)
+  const int64_t nstages = (b_hi - b_lo + COL_CB - 1) / COL_CB;
+  const f32x4 *Pv = reinterpret_cast<const f32x4 *>(P);
+  f32x4 *stage_v = reinterpret_cast<f32x4 *>(smem);
+  // staged float4 number f = tid + 256·i of a stage lies in block cb = f / (NG·64) of that stage
+  int s_cb[NG], s_off[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    const int f = i * 256 + tid;
+    s_cb[i] = f / (NG * 64);
+    s_off[i] = f - s_cb[i] * (NG * 64);
+  }
+  f32x4 rs[NG];
+#pragma unroll
+  for (int i = 0; i < NG; ++i) {
+    int64_t b = b_lo + s_cb[i];
+    b = b < b_hi ? b : b_hi - 1;
+    rs[i] = Pv[b * (NG * 64) + s_off[i]];
+  }
+#pragma unroll
+  for (int i = 0; i < NG; ++i) stage_v[i * 256 + tid] = rs[i];
+  __syncthreads();
+
+  int cur = 0;
+  for (int64_t st = 0; st < nstages; ++st) {
+    const bool more = st + 1 < nstages;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NG; ++i) {
+        int64_t b = b_lo + (st + 1) * COL_CB + s_cb[i];
+        b = b < b_hi ? b : b_hi - 1;
+        rs[i] = Pv[b * (NG * 64) + s_off[i]];
+      }
+    }
+    const float4 *sbuf = stage + cur * STAGE_F4;
+#pragma unroll
+    for (int cb = 0; cb < COL_CB; ++cb) {
+      const int64_t b = b_lo + st * COL_CB + cb;
+      if (b < b_hi) {
+        float4 a[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) a[g] = sbuf[(cb * NG + g) * 64 + lane];
+        collect_step<NG>(a, bq, b, NB, self_blk, self_e, tail_vm, Tq, wb, buf, cursor, q0, n_q, cap, lane);
+      }
+    }
+    if (more) {
+      f32x4 *dbuf = stage_v + (cur ^ 1) * STAGE_F4;  // last read in stage st-1: every wave is past that barrier
+#pragma unroll
+      for (int i = 0; i < NG; ++i) dbuf[i * 256 + tid] = rs[i];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
+}
+
+// sample threshold: T[q] = approximate distance of the m-th best sampled candidate (+inf if fewer)
+__global__ void knn_threshold_kernel(const u64 *__restrict__ skeys, const int *__restrict__ scnt, int64_t n_q,
+                                     int KPS, int m, float *__restrict__ T) {
+  const int64_t ql = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (ql >= n_q) return;
+  T[ql] = scnt[ql] >= m ? ordered_to_f32((unsigned)(skeys[ql * KPS + m - 1] >> 32)) : INFINITY;
+}
+
+// ---- merge: the K' smallest keys of a query's candidate lists -------------------------------------
+// One wave per query.  Input: S lists of at most `lcap` keys each (route 1a: the per-split select
+// lists; route 1b: S = 1, the collect buffer, whose cursor may exceed lcap = overflow).  Output:
+// keys[q][0..c) sorted, cnts[q] = c = min(total, KP) and bound[q] = the approximate distance
+// below which EVERY candidate is in keys[q] (+inf: all admissible candidates are listed).
+// A query whose buffer overflowed or holds fewer than k keys goes straight to the fallback.
+__global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ skeys, const int *__restrict__ scnt,
+                                                        const float *__restrict__ T, int64_t n_q, int S, int lcap,
+                                                        int KP, int k, u64 *__restrict__ keys, int *__restrict__ cnts,
+                                                        float *__restrict__ bound, int *__restrict__ nflag,
+                                                        int *__restrict__ flagged, double *__restrict__ bound_d,
+                                                        int *__restrict__ bound_i) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t ql = (int64_t)blockIdx.x * 4 + wave;
+  if (ql >= n_q) return;
+  u64 *buf = reinterpret_cast<u64 *>(smem) + (size_t)wave * S * lcap;
+  int c = 0;
+  bool overflow = false, all_listed = true;
+  for (int sp = 0; sp < S; ++sp) {
+    int cs = scnt[ql * S + sp];
+    if (cs > lcap) { overflow = true; cs = lcap; }
+    if (cs >= KP) all_listed = false;   // a full select list may have dropped candidates
+    for (int i = lane; i < cs; i += 64) buf[c + i] = skeys[(ql * S + sp) * (int64_t)lcap + i];
+    c += cs;
+  }
+  const float Tq = T ? T[ql] : INFINITY;   // route 1b: nothing above T was collected
+  if (T && Tq < INFINITY) all_listed = false;
+  if (overflow || c < k) {
+    if (lane == 0) {
+      const int pos = atomicAdd(nflag, 1);
+      flagged[pos] = (int)ql;
+      bound_d[ql] = INFINITY;
+      bound_i[ql] = 0x7fffffff;
+      cnts[ql] = 0;
+    }
+    return;
+  }
+  __builtin_amdgcn_wave_barrier();
+  for (int j = lane; j < c; j += 64) {
+    const u64 e = buf[j];
+    int rk = 0;
+    for (int i = 0; i < c; ++i) rk += (buf[i] < e) ? 1 : 0;
+    if (rk < KP) keys[ql * KP + rk] = e;
+    if (rk == KP - 1) bound[ql] = fminf(ordered_to_f32((unsigned)(e >> 32)), Tq);
+  }
+  if (lane == 0) {
+    cnts[ql] = c < KP ? c : KP;
+    if (c < KP) bound[ql] = all_listed ? INFINITY : Tq;
   }
 }
 
@@ -303,8 +643,9 @@ __device__ __forceinline__ bool key_less(double da, int ia, double db, int ib) {
 // one wave per query; dynamic LDS per wave: double xq[d], double dd[KP], int ii[KP]
 __global__ __launch_bounds__(256) void knn_rerank_kernel(
     const float *__restrict__ x, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
-    int d, int64_t q_begin, int64_t n_q, const u64 *__restrict__ keys, const int *__restrict__ cnts, int KP,
-    int k, double eps_coef, int force_flag, int32_t *__restrict__ out_idx, float *__restrict__ out_dist,
+    int d, int64_t q_begin, int64_t n_q, const u64 *__restrict__ keys, const int *__restrict__ cnts,
+    const float *__restrict__ bound, int KP, int k, double eps_coef, int force_flag,
+    int32_t *__restrict__ out_idx, float *__restrict__ out_dist,
     int *__restrict__ nflag, int *__restrict__ flagged, double *__restrict__ bound_d,
     int *__restrict__ bound_i) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -336,14 +677,10 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
       out_dist[ql * k + rk] = (float)dj;
     }
     if (rk == k - 1) {
-      bool certified;
-      if (c < KP) {
-        certified = true;  // every admissible point is in the list
-      } else {
-        const float tau = ordered_to_f32((unsigned)(keys[ql * KP + KP - 1] >> 32));
-        const double eps = eps_coef * ((double)norms[q] + (double)__uint_as_float(*maxnorm_bits));
-        certified = dj < (double)tau - eps;
-      }
+      // every candidate outside keys[ql] has approximate distance >= bound[ql]
+      const float tau = bound[ql];
+      const double eps = eps_coef * ((double)norms[q] + (double)__uint_as_float(*maxnorm_bits));
+      const bool certified = tau == INFINITY || dj < (double)tau - eps;
       if (!certified || force_flag) {
         const int pos = atomicAdd(nflag, 1);
         flagged[pos] = (int)ql;
@@ -439,14 +776,6 @@ __global__ __launch_bounds__(FB_THREADS) void knn_exact_scan_kernel(
 }
 
 // ---- host orchestration ----------------------------------------------------------------------
-template <int NG>
-static void launch_select(int64_t nwaves, size_t lds, const float4 *P, const float *norms, const float *x,
-                          const float *mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q,
-                          int include_self, int KP, int CAP, u64 *keys, int *cnts) {
-  hipLaunchKernelGGL(knn_select_kernel<NG>, dim3((unsigned)nwaves), dim3(64), lds, stream(), P, norms, x, mu, N,
-                     d, NB, q_begin, n_q, include_self, KP, CAP, keys, cnts);
-}
-
 // Grow-only device scratch kept across calls (hipMalloc/hipFree per call cost ~10 ms of the
 // 100k-cell step).  Never freed: the process owns one set.
 struct DevBuf {
@@ -462,6 +791,63 @@ struct DevBuf {
   }
   template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
+
+struct SelectArgs {
+  const float4 *P; const float *norms, *x, *mu;
+  int64_t N; int d; int64_t NB, q_begin, n_q; int include_self;
+};
+
+static int run_select(int NG, const SelectArgs &a, int KP, int CAP, int S, int64_t NBs, int bstride, u64 *keys,
+                      int *cnts) {
+  const int64_t nwaves = ceil_div(a.n_q, 32) * S;
+  const size_t lds = sizeof(u64) * 32 * (size_t)(CAP + 1) + 32 * 8;
+#define CC_SEL(NGV)                                                                                          \
+  case NGV:                                                                                                  \
+    hipLaunchKernelGGL(knn_select_kernel<NGV>, dim3((unsigned)nwaves), dim3(64), lds, stream(), a.P, a.norms, \
+                       a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, KP, CAP, S, NBs, bstride, \
+                       keys, cnts);                                                                          \
+    break;
+  switch (NG) {
+    CC_SEL(1) CC_SEL(2) CC_SEL(3) CC_SEL(5) CC_SEL(9) CC_SEL(17)
+    default: CC_REQUIRE(false, "knn: no kernel for NG=%d", NG);
+  }
+#undef CC_SEL
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+static int run_collect(int NG, const SelectArgs &a, const float *T, int S, int64_t NBs, int cap, u64 *buf,
+                       int *cursor) {
+  const int64_t nwg = ceil_div(a.n_q, 128) * S;
+#define CC_COL(NGV)                                                                                           \
+  case NGV: {                                                                                                 \
+    const size_t lds = sizeof(float4) * 2 * COL_CB * NGV * 64 + (sizeof(u64) + sizeof(int)) * 4 * COL_WB;     \
+    if (lds > 64 * 1024)                                                                                      \
+      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_collect_kernel<NGV>),                    \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+    hipLaunchKernelGGL(knn_collect_kernel<NGV>, dim3((unsigned)nwg), dim3(256), lds, stream(), a.P, a.norms,  \
+                       a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, T, S, NBs, cap, buf,      \
+                       cursor);                                                                               \
+    break;                                                                                                    \
+  }
+  switch (NG) {
+    CC_COL(1) CC_COL(2) CC_COL(3) CC_COL(5) CC_COL(9) CC_COL(17)
+    default: CC_REQUIRE(false, "knn: no kernel for NG=%d", NG);
+  }
+#undef CC_COL
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+// split the NB candidate blocks into S contiguous ranges of NBs blocks (last may be short)
+static void make_splits(int64_t NB, int want, int *S, int64_t *NBs) {
+  int s = want < 1 ? 1 : want;
+  while (s > 1 && NB / s < 16) --s;
+  int64_t nbs = ceil_div(NB, s);
+  while (s > 1 && (int64_t)(s - 1) * nbs >= NB) { --s; nbs = ceil_div(NB, s); }
+  *S = s;
+  *NBs = nbs;
+}
 
 int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, int k, int include_self,
             int32_t *h_idx, float *h_dist) {
@@ -484,10 +870,21 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   int KP = 0;
   for (int o : kp_opts)
     if (o >= k + 14) { KP = o; break; }
-  const int CAP = KP + 64;
   const int64_t NB = ceil_div(N, 32);
+  const int64_t tiles = ceil_div(n_q, 32);
 
-  static DevBuf P, norms, maxn, keys, cnts, oidx, odist, nflag, flagged, bnd_d, bnd_i, partial, mu;
+  // Route 1b (sampled threshold + collect) for large candidate sets and moderate k; route 1a
+  // (full select with running threshold) otherwise.  Sample = every 8th candidate block, T = the
+  // m-th best of the sample (m = max(16, k)): the number of candidates below T is ~Gamma(m)·8, i.e.
+  // 8m on average, >= k and <= 4·8m except with probability < 1e-5 per query; either miss only
+  // sends that query to the float64 fallback.
+  const int SAMPLE = 8;
+  const int m = k > 16 ? k : 16;
+  const bool sampled = !g_force_route_a && NB >= 64 * SAMPLE && N >= (int64_t)64 * SAMPLE * m && k <= 50;
+  const int col_cap = 4 * SAMPLE * m;   // collect buffer entries per query
+
+  static DevBuf P, norms, maxn, keys, cnts, bound, skeys, scnts, Tq, cbuf, ccur, oidx, odist, nflag, flagged, bnd_d,
+      bnd_i, partial, mu;
   int rc;
   if ((rc = P.alloc(sizeof(float4) * (size_t)(NB * NG * 64)))) return rc;
   if ((rc = norms.alloc(sizeof(float) * (size_t)N))) return rc;
@@ -496,6 +893,7 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   if ((rc = mu.alloc(sizeof(float) * (size_t)d))) return rc;
   if ((rc = keys.alloc(sizeof(u64) * (size_t)(n_q * KP)))) return rc;
   if ((rc = cnts.alloc(sizeof(int) * (size_t)n_q))) return rc;
+  if ((rc = bound.alloc(sizeof(float) * (size_t)n_q))) return rc;
   if ((rc = oidx.alloc(sizeof(int32_t) * (size_t)(n_q * k)))) return rc;
   if ((rc = odist.alloc(sizeof(float) * (size_t)(n_q * k)))) return rc;
   if ((rc = nflag.alloc(16))) return rc;
@@ -519,20 +917,51 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
                        mu.as<float>(), norms.as<float>(), N, d, NG, NB, P.as<float4>());
     CC_HIP(hipGetLastError());
   }
+  const SelectArgs sa{P.as<float4>(), norms.as<float>(), d_x, mu.as<float>(), N, d, NB, q_begin, n_q, include_self};
   {
-    const int64_t nwaves = ceil_div(n_q, 32);
-    const size_t lds = sizeof(u64) * 32 * (size_t)(CAP + 1) + 32 * 8;
     ProfScope prof(CC_PROF_KNN_SELECT, 2.0 * (double)n_q * (double)N * (double)d);
-#define CC_SEL(NGV)                                                                                         \
-  case NGV:                                                                                                 \
-    launch_select<NGV>(nwaves, lds, P.as<float4>(), norms.as<float>(), d_x, mu.as<float>(), N, d, NB,       \
-                       q_begin, n_q, include_self, KP, CAP, keys.as<u64>(), cnts.as<int>());                \
-    break;
-    switch (NG) {
-      CC_SEL(1) CC_SEL(2) CC_SEL(3) CC_SEL(5) CC_SEL(9) CC_SEL(17)
-      default: CC_REQUIRE(false, "knn: no kernel for NG=%d", NG);
+    int S = 1, lcap = KP;
+    int64_t NBs = NB;
+    const float *Tptr = nullptr;
+    if (sampled) {
+      // 1b-i: threshold from the sample (select with m-entry lists over every 8th block)
+      const int KPS = (int)round_up(m, 16), CAPS = KPS + 16;
+      if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS)))) return rc;
+      if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q))) return rc;
+      if ((rc = Tq.alloc(sizeof(float) * (size_t)n_q))) return rc;
+      if ((rc = run_select(NG, sa, KPS, CAPS, 1, NB, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) return rc;
+      hipLaunchKernelGGL(knn_threshold_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(),
+                         skeys.as<u64>(), scnts.as<int>(), n_q, KPS, m, Tq.as<float>());
+      // 1b-ii: collect over all candidates, 8 splits (one per XCD) or fewer for short scans
+      make_splits(NB, 8, &S, &NBs);
+      if ((rc = cbuf.alloc(sizeof(u64) * (size_t)n_q * (size_t)col_cap))) return rc;
+      if ((rc = ccur.alloc(sizeof(int) * (size_t)n_q))) return rc;
+      CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
+      if ((rc = run_collect(NG, sa, Tq.as<float>(), S, NBs, col_cap, cbuf.as<u64>(), ccur.as<int>()))) return rc;
+      S = 1;
+      lcap = col_cap;
+      Tptr = Tq.as<float>();
+      hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256),
+                         sizeof(u64) * 4 * (size_t)lcap, stream(), cbuf.as<u64>(), ccur.as<int>(), Tptr, n_q, 1, lcap,
+                         KP, k, keys.as<u64>(), cnts.as<int>(), bound.as<float>(), nflag.as<int>(),
+                         flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>());
+    } else {
+      // 1a: full select; enough (tile, split) waves for ~4 rounds over the resident slots
+      const int CAP = KP + 16;
+      const size_t sel_lds = sizeof(u64) * 32 * (size_t)(CAP + 1) + 32 * 8;
+      int64_t waves_per_cu = (int64_t)(160 * 1024 / sel_lds);
+      if (waves_per_cu > 12) waves_per_cu = 12;
+      int want = (int)ceil_div(4 * 256 * waves_per_cu, tiles);
+      make_splits(NB, want > 8 ? 8 : want, &S, &NBs);
+      if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KP) * (size_t)S))) return rc;
+      if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q * (size_t)S))) return rc;
+      if ((rc = run_select(NG, sa, KP, CAP, S, NBs, 1, skeys.as<u64>(), scnts.as<int>()))) return rc;
+      hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256),
+                         sizeof(u64) * 4 * (size_t)S * (size_t)KP, stream(), skeys.as<u64>(), scnts.as<int>(),
+                         (const float *)nullptr, n_q, S, KP, KP, k, keys.as<u64>(), cnts.as<int>(),
+                         bound.as<float>(), nflag.as<int>(), flagged.as<int>(), bnd_d.as<double>(),
+                         bnd_i.as<int>());
     }
-#undef CC_SEL
     CC_HIP(hipGetLastError());
   }
   // fp32 error bound of stage 1 relative to (‖q−μ‖² + ‖c−μ‖²), u = 2^-24:
@@ -545,8 +974,8 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
     ProfScope prof(CC_PROF_KNN_RERANK, 3.0 * (double)n_q * (double)KP * (double)d);
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), per_wave * 4, stream(), d_x,
                        norms.as<float>(), maxn.as<unsigned>(), d, q_begin, n_q, keys.as<u64>(), cnts.as<int>(),
-                       KP, k, eps_coef, g_force_fallback ? 1 : 0, oidx.as<int32_t>(), odist.as<float>(),
-                       nflag.as<int>(), flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>());
+                       bound.as<float>(), KP, k, eps_coef, g_force_fallback ? 1 : 0, oidx.as<int32_t>(),
+                       odist.as<float>(), nflag.as<int>(), flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>());
     CC_HIP(hipGetLastError());
   }
   int h_nflag = 0;
@@ -574,3 +1003,7 @@ extern "C" int cc_knn_force_fallback(int on) {
   return CC_OK;
 }
 extern "C" int64_t cc_knn_last_fallback_count(void) { return cc::g_last_fallback; }
+extern "C" int cc_knn_force_full_select(int on) {
+  cc::g_force_route_a = on != 0;
+  return CC_OK;
+}

@@ -51,3 +51,8 @@ def last_fallback_count():
 
 def force_fallback(on):
     _lib.check(_lib.lib().cc_knn_force_fallback(1 if on else 0))
+
+
+def force_full_select(on):
+    """Test hook: route every call through the full running-threshold select (stage 1a)."""
+    _lib.check(_lib.lib().cc_knn_force_full_select(1 if on else 0))

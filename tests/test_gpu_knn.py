@@ -88,6 +88,41 @@ def test_query_subrange_on_device(hip, oracle_built):
     assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d)
 
 
+@pytest.mark.parametrize('n,d,k,include_self', [(20000, 64, 15, False), (12000, 3, 15, True), (30000, 32, 50, False),
+                                                  (9000, 8, 1, False), (16411, 17, 16, False)])
+def test_sampled_threshold_route(hip, oracle_built, n, d, k, include_self):
+    # large candidate sets take stage 1b (threshold from a 1/8 sample, then collect); the same
+    # inputs through the full select (stage 1a) must give the same bits
+    rng = np.random.default_rng(n + d + k)
+    x = rng.random((n, d), dtype=np.float32)
+    x[rng.choice(n, n // 20, replace=False)] = x[rng.choice(n, n // 20)]        # 5 % exact duplicates
+    qs = rng.choice(n, 300, replace=False)
+    idx, dist = cc.knn_graph(x, k, include_self)
+    n_fb = hipknn.last_fallback_count()
+    for q in qs:
+        wi, wd = ko.knn(x, k, include_self, q_begin=int(q), n_q=1)
+        assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0])
+    hipknn.force_full_select(True)
+    try:
+        idx_a, dist_a = cc.knn_graph(x, k, include_self)
+    finally:
+        hipknn.force_full_select(False)
+    assert np.array_equal(idx, idx_a) and np.array_equal(dist, dist_a)
+    assert n_fb < n // 50                                                       # the threshold rarely misses
+
+
+def test_sampled_route_clustered_and_sorted_data(hip, oracle_built):
+    # cells sorted by cluster (index-correlated neighbours) and tight clusters far from the origin
+    rng = np.random.default_rng(99)
+    centres = rng.random((40, 16), dtype=np.float32) * 50 + 100
+    lab = np.sort(rng.integers(0, 40, 24000))
+    x = (centres[lab] + rng.standard_normal((24000, 16)).astype(np.float32) * 0.01).astype(np.float32)
+    idx, dist = cc.knn_graph(x, 15)
+    for q in rng.choice(24000, 200, replace=False):
+        wi, wd = ko.knn(x, 15, q_begin=int(q), n_q=1)
+        assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0])
+
+
 def test_k_too_large_is_refused(hip):
     x = np.random.default_rng(0).random((10, 4), dtype=np.float32)
     with pytest.raises(ValueError):

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""kNN-only timing on synthetic encodings in HBM (diagnostic)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from cellcomm_amd import _lib
+from cellcomm_amd.knn import knn_graph_device
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
+d = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+k = int(sys.argv[3]) if len(sys.argv) > 3 else 15
+nq = int(sys.argv[4]) if len(sys.argv) > 4 else n
+reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
+_lib.ensure_init(0)
+x = torch.rand((n, d), device='cuda'); torch.cuda.synchronize()
+knn_graph_device(x.data_ptr(), n, d, k, 0, nq)
+_lib.profile_enable(True); _lib.profile_reset()
+t0 = time.perf_counter()
+for _ in range(reps):
+    knn_graph_device(x.data_ptr(), n, d, k, 0, nq)
+t1 = time.perf_counter()
+p = _lib.profile_snapshot()
+print(f'n={n} d={d} k={k} nq={nq}: {1e3*(t1-t0)/reps:.2f} ms/call', {kk: round(v['ms']/reps, 3) for kk, v in p.items() if v['launches']},
+      'fallback', _lib.lib().cc_knn_last_fallback_count())
