@@ -95,6 +95,12 @@ struct WShape { int64_t rows, cols; };
 
 struct Encoder {
   int arch = 0, G = 0, E = 0;
+  int dtype = CC_DTYPE_F32;
+  PackedWeight16 L16[2];           // layers 1-2 for the fp16-MFMA modes
+  _Float16 *xh = nullptr, *h1h = nullptr, *h1l = nullptr;
+  int64_t ldxh = 0, ld1h = 0;
+  int *d_flag = nullptr;           // gather raises it when a value is not an fp16 number
+  int64_t fallback_passes = 0;
   int64_t w0 = 0, w1 = 0;  // hidden widths of the first two layers
   int64_t batch = 8192;
   std::vector<WShape> shapes;
@@ -167,11 +173,27 @@ static int encoder_pack(Encoder *e) {
     if ((rc = pack_weight(e->w[4].data(), e->w[5].data(), 300, 1000, 150, &e->L[2]))) return rc;
     if ((rc = pack_weight(e->w[6].data(), e->w[7].data(), 150, 0, e->E, &e->L[3]))) return rc;
   }
+  if (e->dtype != CC_DTYPE_F32) {
+    // layers 1-2 again, split into fp16 hi/lo planes for the fp16 matrix cores
+    if (e->arch == CC_ARCH_CONT) {
+      if ((rc = pack_weight16(e->w[0].data(), e->w[1].data(), e->G, 0, e->w0, &e->L16[0]))) return rc;
+      if ((rc = pack_weight16(e->w[2].data(), e->w[3].data(), e->w0, e->G, e->w1, &e->L16[1]))) return rc;
+    } else {
+      if ((rc = pack_weight16(e->w[0].data(), e->w[1].data(), e->G, 0, 1000, &e->L16[0]))) return rc;
+    }
+  }
   e->dirty = false;
   return CC_OK;
 }
 
 static void encoder_free_ws(Encoder *e) {
+  _Float16 **hb[] = {&e->xh, &e->h1h, &e->h1l};
+  for (auto b : hb) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  if (e->d_flag) (void)hipFree(e->d_flag);
+  e->d_flag = nullptr;
   float **bufs[] = {&e->x, &e->h1, &e->h2, &e->h3, &e->h4};
   for (auto b : bufs) {
     if (*b) (void)hipFree(*b);
@@ -203,7 +225,47 @@ static int encoder_ensure_ws(Encoder *e, int64_t rows) {
   if ((rc = alloc_zero(&e->h3, rows, e->ld3))) return rc;
   if ((rc = alloc_zero(&e->h4, rows, e->ld3))) return rc;
   CC_HIP(hipMalloc(&e->d_row_ids, sizeof(int64_t) * (size_t)rows));
+  if (e->dtype != CC_DTYPE_F32) {
+    e->ldxh = round_up(e->G, 64);
+    e->ld1h = e->w0 == 0 ? 64 : round_up(e->w0, 64);
+    const size_t bx = sizeof(_Float16) * (size_t)(rows * e->ldxh), b1 = sizeof(_Float16) * (size_t)(rows * e->ld1h);
+    CC_HIP(hipMalloc(&e->xh, bx));
+    CC_HIP(hipMalloc(&e->h1h, b1));
+    CC_HIP(hipMalloc(&e->h1l, b1));
+    CC_HIP(hipMemsetAsync(e->xh, 0, bx, stream()));
+    CC_HIP(hipMemsetAsync(e->h1h, 0, b1, stream()));
+    CC_HIP(hipMemsetAsync(e->h1l, 0, b1, stream()));
+    CC_HIP(hipMalloc(&e->d_flag, sizeof(int)));
+  }
   e->ws_rows = rows;
+  return CC_OK;
+}
+
+// Layers 1-2 on the fp16 matrix cores from M rows already in e->xh (fp16); tail as fp32.
+static int encoder_forward16(Encoder *e, int64_t M, float *out) {
+  int rc;
+  const bool split = e->dtype == CC_DTYPE_F16X2;
+  const int nt = split ? 2 : 1;
+  if (e->arch == CC_ARCH_CONT) {
+    const GemmSeg16 s0[1] = {{e->xh, e->ldxh, 0, nt}};
+    if ((rc = launch_gemm16(s0, 1, M, e->L16[0], e->h1h, split ? e->h1l : nullptr, e->ld1h, 1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
+    GemmSeg16 s1[3];
+    int n1 = 0;
+    s1[n1++] = {e->h1h, e->ld1h, 0, nt};
+    if (split) s1[n1++] = {e->h1l, e->ld1h, 0, 1};   // third product term A_lo·W_hi of the sigmoid outputs
+    s1[n1++] = {e->xh, e->ldxh, 1, nt};
+    if ((rc = launch_gemm16(s1, n1, M, e->L16[1], e->h2, nullptr, e->ld2, 0, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->h2, e->ld2, nullptr, 0, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], e->h4, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h4, e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+  } else {
+    const GemmSeg16 s0[1] = {{e->xh, e->ldxh, 0, nt}};
+    if ((rc = launch_gemm16(s0, 1, M, e->L16[0], e->h1, nullptr, e->ld1, 0, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
+    if ((rc = launch_gemm(e->h1, e->ld1, nullptr, 0, M, e->L[1], e->h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->h2, e->ld2, e->h1, e->ld1, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_row_softmax(out, M, e->E, e->E))) return rc;
+  }
   return CC_OK;
 }
 
@@ -248,6 +310,7 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   int rc;
   if ((rc = check_rows(c, row_ids, row_start, n))) return rc;
   if (e->dirty && (rc = encoder_pack(e))) return rc;
+  e->fallback_passes = 0;
   if (n == 0) return CC_OK;
   const int64_t B = n < e->batch ? n : e->batch;
   if ((rc = encoder_ensure_ws(e, B))) return rc;
@@ -259,10 +322,26 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
       CC_HIP(hipMemcpyAsync(e->d_row_ids, row_ids + off, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, stream()));
       d_ids = e->d_row_ids;
     }
-    if ((rc = launch_gather(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start + off, m, e->G, e->ldx, e->x,
-                            nnz_per_row * (double)m)))
-      return rc;
-    if ((rc = encoder_forward(e, m, dev_out + off * e->E))) return rc;
+    bool fp32_pass = e->dtype == CC_DTYPE_F32;
+    if (!fp32_pass) {
+      CC_HIP(hipMemsetAsync(e->d_flag, 0, sizeof(int), stream()));
+      if ((rc = launch_gather_f16(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start + off, m, e->G,
+                                  e->ldxh, e->xh, e->d_flag, nnz_per_row * (double)m)))
+        return rc;
+      if (e->dtype == CC_DTYPE_F16X2) {   // the 2-term raw-input product needs fp16-exact values
+        int flag = 0;
+        CC_HIP(hipMemcpyAsync(&flag, e->d_flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        CC_HIP(hipStreamSynchronize(stream()));
+        if (flag) { fp32_pass = true; e->fallback_passes += 1; }
+      }
+      if (!fp32_pass && (rc = encoder_forward16(e, m, dev_out + off * e->E))) return rc;
+    }
+    if (fp32_pass) {
+      if ((rc = launch_gather(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start + off, m, e->G, e->ldx,
+                              e->x, nnz_per_row * (double)m)))
+        return rc;
+      if ((rc = encoder_forward(e, m, dev_out + off * e->E))) return rc;
+    }
   }
   CC_HIP(hipStreamSynchronize(stream()));
   return CC_OK;
@@ -319,10 +398,10 @@ int cc_synchronize(void) {
 int cc_encoder_create(int arch, int G, int E, int dtype, void **enc) {
   CC_REQUIRE(enc != nullptr, "enc is NULL");
   CC_REQUIRE(arch == CC_ARCH_CONT || arch == CC_ARCH_CLS, "unknown encoder arch %d", arch);
-  CC_REQUIRE(dtype == CC_DTYPE_F32, "unsupported dtype %d (only float32)", dtype);
+  CC_REQUIRE(dtype == CC_DTYPE_F32 || dtype == CC_DTYPE_F16 || dtype == CC_DTYPE_F16X2, "unsupported dtype %d", dtype);
   CC_REQUIRE(G >= 1 && E >= 1, "gene_size=%d and encoding_size=%d must be >= 1", G, E);
   Encoder *e = new Encoder();
-  e->arch = arch; e->G = G; e->E = E;
+  e->arch = arch; e->G = G; e->E = E; e->dtype = dtype;
   encoder_shapes(e);
   *enc = e;
   return CC_OK;
@@ -333,6 +412,7 @@ void cc_encoder_free(void *enc) {
   Encoder *e = static_cast<Encoder *>(enc);
   encoder_free_ws(e);
   for (auto &l : e->L) free_weight(&l);
+  for (auto &l : e->L16) free_weight16(&l);
   delete e;
 }
 
@@ -358,6 +438,8 @@ int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, 
   e->dirty = true;
   return CC_OK;
 }
+
+int64_t cc_encoder_fp32_fallback_passes(void *enc) { return static_cast<Encoder *>(enc)->fallback_passes; }
 
 int cc_encoder_set_batch(void *enc, int64_t batch_rows) {
   CC_REQUIRE(batch_rows >= 1, "batch_rows must be >= 1");
@@ -481,6 +563,7 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
   CC_REQUIRE(n >= 0, "negative row count");
   int rc;
   if (e->dirty && (rc = encoder_pack(e))) return rc;
+  e->fallback_passes = 0;
   if (n == 0) return CC_OK;
   const int64_t B = n < e->batch ? n : e->batch;
   if ((rc = encoder_ensure_ws(e, B))) return rc;
@@ -494,7 +577,19 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
       rc = CC_EHIP;
       break;
     }
-    rc = encoder_forward(e, m, d_out + off * e->E);
+    bool fp32_pass = e->dtype == CC_DTYPE_F32;
+    if (!fp32_pass) {
+      int flag = 0;
+      if (hipMemsetAsync(e->d_flag, 0, sizeof(int), stream()) != hipSuccess) { set_error("memset failed"); rc = CC_EHIP; break; }
+      rc = launch_convert_f16(e->x, e->ldx, m, e->G, e->xh, e->ldxh, e->d_flag);
+      if (rc == CC_OK && e->dtype == CC_DTYPE_F16X2) {
+        if (hipMemcpyAsync(&flag, e->d_flag, sizeof(int), hipMemcpyDeviceToHost, stream()) != hipSuccess ||
+            hipStreamSynchronize(stream()) != hipSuccess) { set_error("flag read failed"); rc = CC_EHIP; break; }
+        if (flag) { fp32_pass = true; e->fallback_passes += 1; }
+      }
+      if (rc == CC_OK && !fp32_pass) rc = encoder_forward16(e, m, d_out + off * e->E);
+    }
+    if (rc == CC_OK && fp32_pass) rc = encoder_forward(e, m, d_out + off * e->E);
     // the staging buffer is reused by the next pass
     if (rc == CC_OK && hipStreamSynchronize(stream()) != hipSuccess) {
       set_error("stream synchronise failed in cc_encode_dense");

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -79,6 +80,29 @@ void free_weight(PackedWeight *w);
 int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M,
                 const PackedWeight &W, float *C, int64_t ldc, int act, int prof_class);
 int launch_row_softmax(float *X, int64_t M, int E, int64_t ld);
+
+// gemm16.hip — layers 1/2 on the fp16 matrix cores (CC_DTYPE_F16 / CC_DTYPE_F16X2)
+struct PackedWeight16 {
+  void *d_w = nullptr;      // [NT][KT][hi|lo][8][128][8] fp16
+  float *d_bias = nullptr;  // [NT*128]
+  float scale = 1.f;        // power of two applied to W before the fp16 split
+  int64_t K1 = 0, K2 = 0, KT1 = 0, KT2 = 0, N = 0, NT = 0;
+};
+struct GemmSeg16 {
+  const void *A;   // fp16 [M x lda]
+  int64_t lda;     // in halfs, >= KT·64, zero beyond K
+  int which;       // 0: multiplies weight rows [0,K1), 1: rows [K1,K1+K2)
+  int nterms;      // 1: W_hi, 2: W_hi + W_lo
+};
+int pack_weight16(const float *w, const float *bias, int64_t K1, int64_t K2, int64_t N, PackedWeight16 *out);
+void free_weight16(PackedWeight16 *w);
+int launch_gemm16(const GemmSeg16 *segs, int nsegs, int64_t M, const PackedWeight16 &W, void *C, void *C_lo,
+                  int64_t ldc, int out_fp16, int act, int prof_class);
+int launch_convert_f16(const float *d_x, int64_t ldx, int64_t M, int G, void *d_out_half, int64_t ldo, int *d_inexact);
+// gather.hip — fp16 output; *d_inexact is OR-ed with 1 when a value is not exactly an fp16 number
+int launch_gather_f16(const int64_t *d_indptr, const int32_t *d_indices, const float *d_vals,
+                      const int32_t *d_chunk_rel, const int64_t *d_row_ids, int64_t row_start, int64_t n, int G,
+                      int64_t ld, void *d_out_half, int *d_inexact, double nnz_hint);
 
 // knn.hip
 int knn_run(const float *d_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q, int k,

@@ -78,6 +78,51 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_kernel(
   for (int i = tid; i < n4; i += GATHER_THREADS) orow[i] = tile4[i];
 }
 
+// fp16 output variant (CC_DTYPE_F16 / F16X2 encoders): same staging, the tile leaves as 8 halfs per
+// lane; *inexact is raised when a value does not survive the round trip through fp16.
+__global__ __launch_bounds__(GATHER_THREADS) void csr_gather_f16_kernel(
+    const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
+    const float *__restrict__ vals, const int32_t *__restrict__ chunk_rel, int nc1,
+    const int64_t *__restrict__ row_ids, int64_t row_start, int nchunks, int64_t ld,
+    _Float16 *__restrict__ out, int *__restrict__ inexact) {
+  __shared__ __attribute__((aligned(16))) float tile[GATHER_CH];
+  const int tid = threadIdx.x;
+  const int64_t r = blockIdx.x / nchunks;
+  const int chunk = blockIdx.x % nchunks;
+  const int64_t row = row_ids ? row_ids[r] : row_start + r;
+  const int64_t c0 = (int64_t)chunk * GATHER_CH;
+  const int64_t c1 = (c0 + GATHER_CH < ld) ? c0 + GATHER_CH : ld;
+  const int64_t beg = indptr[row];
+  const int32_t *rel = chunk_rel + row * nc1;
+  const int64_t lo = beg + rel[chunk < nc1 - 1 ? chunk : nc1 - 1];
+  const int64_t hi = beg + rel[chunk + 1 < nc1 - 1 ? chunk + 1 : nc1 - 1];
+
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 *tile4 = reinterpret_cast<float4 *>(tile);
+#pragma unroll
+  for (int i = tid; i < GATHER_CH / 4; i += GATHER_THREADS) tile4[i] = z;
+  __syncthreads();
+  bool bad = false;
+  for (int64_t p = lo + tid; p < hi; p += GATHER_THREADS) {
+    const float v = vals[p];
+    bad |= (float)(_Float16)v != v;
+    tile[indices[p] - (int32_t)c0] = v;
+  }
+  if (__any(bad) && (tid & 63) == 0) atomicOr(inexact, 1);
+  __syncthreads();
+
+  using h8v = __attribute__((ext_vector_type(8))) _Float16;
+  h8v *orow = reinterpret_cast<h8v *>(out + r * ld + c0);
+  const int n8 = (int)((c1 - c0) >> 3);
+  for (int i = tid; i < n8; i += GATHER_THREADS) {
+    const float4 a = tile4[2 * i], b = tile4[2 * i + 1];
+    h8v o;
+    o[0] = (_Float16)a.x; o[1] = (_Float16)a.y; o[2] = (_Float16)a.z; o[3] = (_Float16)a.w;
+    o[4] = (_Float16)b.x; o[5] = (_Float16)b.y; o[6] = (_Float16)b.z; o[7] = (_Float16)b.w;
+    orow[i] = o;
+  }
+}
+
 int gather_chunk_count(int G) { return (int)ceil_div(G, GATHER_CH) + 1; }
 
 int build_chunk_index(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, int G,
@@ -104,6 +149,49 @@ int launch_gather(const int64_t *d_indptr, const int32_t *d_indices, const float
   ProfScope prof(CC_PROF_GATHER, 8.0 * nnz_hint + 8.0 * (double)n + 4.0 * (double)ld * (double)n);
   hipLaunchKernelGGL(csr_gather_kernel, dim3((unsigned)nblocks), dim3(GATHER_THREADS), 0, stream(),
                      d_indptr, d_indices, d_vals, d_chunk_rel, nc1, d_row_ids, row_start, nchunks, ld, d_out);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+// dense fp32 rows (cc_encode_dense) -> fp16 pass buffer, same exactness flag
+__global__ void convert_f32_f16_kernel(const float *__restrict__ x, int64_t ldx, int64_t M, int G,
+                                       _Float16 *__restrict__ out, int64_t ldo, int *__restrict__ inexact) {
+  const int64_t total = M * G;
+  bool bad = false;
+  for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = t / G;
+    const int col = (int)(t % G);
+    const float v = x[row * ldx + col];
+    const _Float16 hv = (_Float16)v;
+    bad |= (float)hv != v;
+    out[row * ldo + col] = hv;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(inexact, 1);
+}
+
+int launch_convert_f16(const float *d_x, int64_t ldx, int64_t M, int G, void *d_out_half, int64_t ldo, int *d_inexact) {
+  if (M == 0) return CC_OK;
+  int64_t blocks = ceil_div(M * G, 256);
+  if (blocks > 8192) blocks = 8192;
+  hipLaunchKernelGGL(convert_f32_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_x, ldx, M, G,
+                     static_cast<_Float16 *>(d_out_half), ldo, d_inexact);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+int launch_gather_f16(const int64_t *d_indptr, const int32_t *d_indices, const float *d_vals,
+                      const int32_t *d_chunk_rel, const int64_t *d_row_ids, int64_t row_start, int64_t n, int G,
+                      int64_t ld, void *d_out_half, int *d_inexact, double nnz_hint) {
+  if (n == 0) return CC_OK;
+  CC_REQUIRE(ld % 8 == 0 && ld >= G, "gather: ld=%lld must be a multiple of 8 and >= G=%d", (long long)ld, G);
+  const int nchunks = (int)ceil_div(ld, GATHER_CH);
+  const int nc1 = gather_chunk_count(G);
+  const int64_t nblocks = n * nchunks;
+  CC_REQUIRE(nblocks < (int64_t)2147483647, "gather: grid too large (%lld blocks)", (long long)nblocks);
+  ProfScope prof(CC_PROF_GATHER, 8.0 * nnz_hint + 8.0 * (double)n + 2.0 * (double)ld * (double)n);
+  hipLaunchKernelGGL(csr_gather_f16_kernel, dim3((unsigned)nblocks), dim3(GATHER_THREADS), 0, stream(), d_indptr,
+                     d_indices, d_vals, d_chunk_rel, nc1, d_row_ids, row_start, nchunks, ld,
+                     static_cast<_Float16 *>(d_out_half), d_inexact);
   CC_HIP(hipGetLastError());
   return CC_OK;
 }

@@ -18,6 +18,8 @@ from .matrix import CellMatrix
 
 ARCH_CONT, ARCH_CLS = 'cont', 'cls'
 _ARCH_CODE = {ARCH_CONT: 0, ARCH_CLS: 1}
+# arithmetic of the two big layers: exact fp32 MFMA (default) | fp16 operands | fp16 hi+lo split operands
+_DTYPE_CODE = {'f32': 0, 'f16': 1, 'f16x2': 2}
 
 
 def hidden_widths(arch, gene_size):
@@ -72,9 +74,12 @@ def _layer_plan(arch, encoding_size, gene_size):
 class HipEncoder:
     name = 'cell_encoder'
 
-    def __init__(self, encoding_size, gene_size, arch=ARCH_CONT, seed=None, batch_rows=None):
+    def __init__(self, encoding_size, gene_size, arch=ARCH_CONT, seed=None, batch_rows=None, dtype='f32'):
         if arch not in _ARCH_CODE:
             raise ValueError(f'unknown encoder arch {arch!r}')
+        if dtype not in _DTYPE_CODE:
+            raise ValueError(f'unknown encoder dtype {dtype!r} (f32, f16 or f16x2)')
+        self.dtype = dtype
         self.arch = arch
         self.encoding_size = int(encoding_size)
         self.gene_size = int(gene_size)
@@ -83,7 +88,7 @@ class HipEncoder:
         self.trainable = False
         lib = _lib.ensure_init()
         self._h = ctypes.c_void_p()
-        _lib.check(lib.cc_encoder_create(_ARCH_CODE[arch], self.gene_size, self.encoding_size, 0,
+        _lib.check(lib.cc_encoder_create(_ARCH_CODE[arch], self.gene_size, self.encoding_size, _DTYPE_CODE[dtype],
                                          ctypes.byref(self._h)))
         if batch_rows:
             _lib.check(lib.cc_encoder_set_batch(self._h, int(batch_rows)))
@@ -185,6 +190,10 @@ class HipEncoder:
             ids = np.ascontiguousarray(ids[row_start:row_start + n], dtype=np.int64)
             ids_ptr, row_start = ids.ctypes.data, 0
         _lib.check(lib.cc_encode_dev(self._h, x.device_handle(), ids_ptr, row_start, n, dev_out_ptr))
+
+    def fp32_fallback_passes(self):
+        """dtype 'f16x2': passes of the last predict whose input was not fp16-exact (ran in fp32)."""
+        return int(_lib.lib().cc_encoder_fp32_fallback_passes(self._h))
 
     def __call__(self, x, training=False):
         return self.predict(x)

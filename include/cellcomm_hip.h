@@ -38,7 +38,9 @@ extern "C" {
 #define CC_ARCH_CONT 0 /* reference src/bigan_cont.py:28-41     */
 #define CC_ARCH_CLS 1  /* reference src/bigan_classify.py:28-40 */
 
-#define CC_DTYPE_F32 0
+#define CC_DTYPE_F32 0   /* exact fp32 products (v_mfma_f32_32x32x2_f32) — the default            */
+#define CC_DTYPE_F16 1   /* layers 1-2 with operands rounded to fp16, fp32 accumulate (config 5)  */
+#define CC_DTYPE_F16X2 2 /* layers 1-2 on fp16 MFMA with hi+lo split operands: fp32-equivalent    */
 
 /* ---- runtime ----------------------------------------------------------- */
 
@@ -69,6 +71,9 @@ int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols);
 int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols);
 /* Rows processed per pass through the layer stack (default 8192). */
 int cc_encoder_set_batch(void *enc, int64_t batch_rows);
+/* CC_DTYPE_F16X2 only: passes of the last cc_encode* call whose input was not exactly
+ * representable in fp16 and therefore ran on the fp32 kernels instead. */
+int64_t cc_encoder_fp32_fallback_passes(void *enc);
 
 /* ---- CSR cell x gene matrix: replaces the dense pivot of
  *      load_matrix (reference src/cell_type_training.py:9-17) ------------- */

@@ -123,3 +123,44 @@ def trainings_encoding_prediction_cls(prediction, encoding_size):
     out = np.zeros((len(am), encoding_size), dtype=np.float32)
     out[np.arange(len(am)), am] = 1.0
     return out
+
+
+def _pow2_scale(w):
+    """The power-of-two scale the fp16 paths apply to a weight matrix before rounding it to
+    fp16 (cellcomm_amd/csrc/gemm16.hip pack_weight16): max|w|*s lands in [2^13, 2^14)."""
+    mx = float(np.max(np.abs(w))) if w.size else 0.0
+    if mx == 0.0 or not np.isfinite(mx):
+        return 1.0
+    _, e = np.frexp(np.float32(mx))
+    return float(2.0 ** (14 - int(e)))
+
+
+def _q16(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float16).astype(np.float64)
+
+
+def forward_f16(arch, weights, x):
+    """Float64 evaluation of what CC_DTYPE_F16 is defined to compute: the raw input, the weights of
+    the first two layers (after their power-of-two scale) and, for the cont arch, the first hidden
+    activation are each rounded once to fp16; everything else as forward().  BASELINE config 5
+    ("fp16 MFMA") is checked against this."""
+    w = [np.asarray(a, dtype=np.float64) for a in weights]
+    xq = _q16(x)
+    if arch == ARCH_CONT:
+        k1, b1, k2, b2, gamma, beta, mean, var, k3, b3, k4, b4, k5, b5 = w
+        s1, s2 = _pow2_scale(k1), _pow2_scale(k2)
+        k1q, k2q = _q16(k1 * s1) / s1, _q16(k2 * s2) / s2
+        h = _q16(_sigmoid(xq @ k1q + b1))
+        c = np.concatenate([h, xq], axis=-1)
+        h = _sigmoid(c @ k2q + b2)
+        h = (h - mean) / np.sqrt(var + BN_EPSILON) * gamma + beta
+        h = _sigmoid(h @ k3 + b3)
+        h = _sigmoid(h @ k4 + b4)
+        return _sigmoid(h @ k5 + b5)
+    k1, b1, k2, b2, k3, b3, k4, b4 = w
+    s1 = _pow2_scale(k1)
+    p = _sigmoid(xq @ (_q16(k1 * s1) / s1) + b1)
+    h = _sigmoid(p @ k2 + b2)
+    c = np.concatenate([h, p], axis=-1)
+    h = _sigmoid(c @ k3 + b3)
+    return _softmax(h @ k4 + b4)
