@@ -1,0 +1,66 @@
+"""One parity test per BASELINE.json config, at the config's own shapes (oracle-checkable subsets
+plus size-independent properties where the full oracle would take too long)."""
+import numpy as np
+import pytest
+
+import cellcomm_amd as cc
+from cellcomm_amd import synth
+from cellcomm_amd.knn import knn_graph_device
+from oracle import encoder_oracle as eo
+from oracle import knn_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+
+def max_rel(got, truth):
+    return float(np.max(np.abs(got.astype(np.float64) - truth) / np.abs(truth)))
+
+
+def test_config2_encode_only_10k_x_20k_latent32(hip):
+    # configs[1]: synthetic 10k cells x 20k genes, latent 32, encode only
+    m, (indptr, indices, values) = synth.synth_csr_device(10000, 20000, seed=7)
+    enc = cc.HipEncoder(32, 20000, 'cont', seed=4321)
+    out = enc.predict(m)
+    assert out.shape == (10000, 32) and np.all(out > 0) and np.all(out < 1)
+    host = cc.CellMatrix(indptr.cpu().numpy(), indices.cpu().numpy(), values.cpu().numpy(), 20000)
+    rows = np.random.default_rng(0).choice(10000, 64, replace=False)
+    truth = eo.forward('cont', enc.get_weights(), host.take(rows).to_dense())
+    assert max_rel(out[rows], truth) <= 1e-4
+    assert np.array_equal(enc.predict(host.take(rows)), out[rows])      # row results are batch independent
+
+
+def test_config4_shard_of_1m_candidates(hip, oracle_built):
+    # configs[3]: 1M cells sharded over 8 GPUs — one rank's kNN: its 125k queries against all 1M
+    # encodings, global indices; 48 seeded queries checked bit-exact against the oracle.
+    import torch
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(5)
+    x = torch.sigmoid(torch.randn((1000000, 64), device='cuda', generator=gen))
+    torch.cuda.synchronize()
+    q_begin, n_q = 875000, 125000
+    idx, dist = knn_graph_device(x.data_ptr(), 1000000, 64, 15, q_begin=q_begin, n_q=n_q)
+    host = x.cpu().numpy()
+    for ql in np.random.default_rng(1).choice(n_q, 48, replace=False):
+        wi, wd = ko.knn(host, 15, q_begin=q_begin + int(ql), n_q=1)
+        assert np.array_equal(idx[ql], wi[0]) and np.array_equal(dist[ql], wd[0])
+    assert np.all(idx != (q_begin + np.arange(n_q))[:, None]) and np.all(np.diff(dist, axis=1) >= 0)
+
+
+def test_config5_fp16_encoder_33k_genes_and_k50(hip, oracle_built):
+    # configs[4]: cont encoder at G = 33000 with fp16 MFMA operands, k = 50 kNN
+    g, e = 33000, 64
+    m = synth.synth_csr(40, g, seed=12)
+    enc = cc.HipEncoder(e, g, 'cont', seed=4321, dtype='f16')
+    ws = enc.get_weights()
+    out = enc.predict(m)
+    assert max_rel(out, eo.forward_f16('cont', ws, m.to_dense())) <= 1e-4
+    import torch
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(9)
+    x = torch.rand((62500, e), device='cuda', generator=gen)             # one of 8 shards of 500k
+    torch.cuda.synchronize()
+    idx, dist = knn_graph_device(x.data_ptr(), 62500, e, 50)
+    host = x.cpu().numpy()
+    for q in np.random.default_rng(2).choice(62500, 64, replace=False):
+        wi, wd = ko.knn(host, 50, q_begin=int(q), n_q=1)
+        assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0])
