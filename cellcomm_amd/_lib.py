@@ -48,6 +48,10 @@ SIGNATURES = {
     'cc_encode': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'cc_encode_dev': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     'cc_encode_dense': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'cc_mtx_load': (c_int, [c_char_p, POINTER(c_void_p)]),
+    'cc_mtx_shape': (c_int, [c_void_p, POINTER(c_int64), POINTER(c_int64), POINTER(c_int64)]),
+    'cc_mtx_export': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'cc_mtx_free': (None, [c_void_p]),
     'cc_knn_l2': (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cc_knn_l2_dev': (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     'cc_knn_force_fallback': (c_int, [c_int]),

@@ -148,11 +148,20 @@ def wrap_device_csr(dev_indptr, dev_indices, dev_vals, n_rows, nnz, n_genes, kee
     return m
 
 
-def load_matrix(matrix_file, verbose=False):
+def load_matrix(matrix_file, verbose=False, engine='native'):
     """10x-style MatrixMarket triplets -> CellMatrix.  Same result as the pivot at
-    reference src/cell_type_training.py:9-17 (see module docstring)."""
+    reference src/cell_type_training.py:9-17 (see module docstring).  engine='native' streams the
+    file through the C++ parser in libcellcomm_hip.so (cc_mtx_load, host only); engine='pandas'
+    is the NumPy/pandas statement of the same semantics."""
     if verbose:
         print(f'============ Loading {matrix_file}...')
+    if engine == 'native':
+        m = _load_matrix_native(matrix_file)
+        if verbose:
+            print(f'============ DONE! barcodes: {m.shape[0]}, genes: {m.shape[1]}')
+        return m
+    if engine != 'pandas':
+        raise ValueError(f'unknown engine {engine!r}')
     df = pd.read_csv(matrix_file, header=None, skiprows=3, sep=r'\s+', names=['gene', 'barcode', 'p'])
     genes, gene_pos = np.unique(df['gene'].to_numpy(), return_inverse=True)
     barcodes, row_pos = np.unique(df['barcode'].to_numpy(), return_inverse=True)
@@ -170,6 +179,26 @@ def load_matrix(matrix_file, verbose=False):
     if verbose:
         print(f'============ DONE! barcodes: {m.shape[0]}, genes: {m.shape[1]}')
     return m
+
+
+def _load_matrix_native(matrix_file):
+    import os
+    lib = _lib.lib()
+    h = ctypes.c_void_p()
+    _lib.check(lib.cc_mtx_load(os.fsencode(os.fspath(matrix_file)), ctypes.byref(h)))
+    try:
+        n_rows, n_genes, nnz = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(lib.cc_mtx_shape(h, ctypes.byref(n_rows), ctypes.byref(n_genes), ctypes.byref(nnz)))
+        indptr = np.empty(n_rows.value + 1, dtype=np.int64)
+        indices = np.empty(nnz.value, dtype=np.int32)
+        vals = np.empty(nnz.value, dtype=np.float32)
+        barcodes = np.empty(n_rows.value, dtype=np.int64)
+        genes = np.empty(n_genes.value, dtype=np.int64)
+        _lib.check(lib.cc_mtx_export(h, indptr.ctypes.data, indices.ctypes.data, vals.ctypes.data,
+                                     barcodes.ctypes.data, genes.ctypes.data))
+    finally:
+        lib.cc_mtx_free(h)
+    return CellMatrix(indptr, indices, vals, n_genes.value, index=barcodes, columns=genes)
 
 
 def load_cells(cells_file, verbose=False):

@@ -105,6 +105,18 @@ int cc_encode_dev(void *enc, void *csr, const int64_t *row_ids, int64_t row_star
  * when cell_data is a DataFrame/ndarray/list). */
 int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out);
 
+/* ---- matrix ingest on the host: replaces pandas read_csv + pivot_table of
+ *      load_matrix (reference src/cell_type_training.py:9-17); needs no GPU ------ */
+
+/* Parse a 10x-style MatrixMarket file (3 lines skipped, then `gene barcode value` triplets)
+ * into CSR with pivot semantics: rows = sorted distinct barcodes, columns = sorted distinct
+ * genes, duplicate entries averaged.  Sizes via cc_mtx_shape, arrays via cc_mtx_export
+ * (indptr[n_rows+1], indices[nnz], vals[nnz], barcodes[n_rows], genes[n_genes] = original ids). */
+int cc_mtx_load(const char *path, void **mtx);
+int cc_mtx_shape(void *mtx, int64_t *n_rows, int64_t *n_genes, int64_t *nnz);
+int cc_mtx_export(void *mtx, int64_t *indptr, int32_t *indices, float *vals, int64_t *barcodes, int64_t *genes);
+void cc_mtx_free(void *mtx);
+
 /* ---- kNN graph: no reference implementation; semantics are
  *      defined by oracle/knn_oracle.c -------------------------------------- */
 

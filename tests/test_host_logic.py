@@ -29,6 +29,51 @@ def _write_mtx(path, triplets):
             f.write(f'{g} {b} {p}\n')
 
 
+@pytest.mark.parametrize('engine', ['native', 'pandas'])
+def test_load_matrix_engines_known_answer(known, engine):
+    m = matrix.load_matrix(MTX, engine=engine)
+    assert m.shape == (5, 5)
+    assert np.array_equal(m.to_dense(), np.array(known['load_matrix']['matrix'], dtype=np.float32))
+
+
+def test_native_parser_edge_cases(tmp_path):
+    path = tmp_path / 'edge.mtx'
+    with open(path, 'w') as f:                # CRLF, tabs, blank lines, float values, unordered, negative ids
+        f.write('%%MatrixMarket\r\n%junk 1 2 3\r\n5 5 5\r\n')
+        f.write('7\t3 2.5\r\n\n  2 3 1e1  \n7 3 3.5\n-1 9 4\n2 1 0\n')
+    want = lo.load_matrix(path)
+    for engine in ('native', 'pandas'):
+        got = matrix.load_matrix(path, engine=engine)
+        assert np.array_equal(got.index, want.index.to_numpy()) and np.array_equal(got.columns, want.columns.to_numpy())
+        assert np.array_equal(got.to_dense(np.float64), want.to_numpy().astype(np.float64))
+    bad = tmp_path / 'bad.mtx'
+    bad.write_text('a\nb\nc\n1 2\n')
+    with pytest.raises(ValueError):
+        matrix.load_matrix(bad)
+    with pytest.raises(ValueError):
+        matrix.load_matrix(tmp_path / 'missing.mtx')
+    empty = tmp_path / 'empty.mtx'
+    empty.write_text('a\nb\nc\n')
+    assert matrix.load_matrix(empty).shape == (0, 0)
+
+
+def test_native_parser_large_file_matches_pandas_engine(tmp_path):
+    rng = np.random.default_rng(8)
+    n, g = 3000, 800
+    m = synth.synth_csr(n, g, density=0.03, seed=4)
+    path = tmp_path / 'big.mtx'
+    rows = np.repeat(np.arange(n), np.diff(m.indptr))
+    with open(path, 'w') as f:
+        f.write('%%MatrixMarket matrix coordinate integer general\n%\n0 0 0\n')
+        order = rng.permutation(len(rows)) if True else np.arange(len(rows))
+        np.savetxt(f, np.stack([m.indices[order] + 1, rows[order] + 1, m.values[order].astype(np.int64)], 1), fmt='%d')
+    a = matrix.load_matrix(path, engine='native')
+    b = matrix.load_matrix(path, engine='pandas')
+    for x, y in ((a.indptr, b.indptr), (a.indices, b.indices), (a.values, b.values), (a.index, b.index), (a.columns, b.columns)):
+        assert np.array_equal(x, y)
+    assert np.array_equal(a.indptr, m.indptr) and np.array_equal(a.indices, m.indices) and np.array_equal(a.values, m.values)
+
+
 def test_load_matrix_equals_pivot_on_ragged_input(tmp_path):
     rng = np.random.default_rng(2)
     trip = [(int(rng.integers(1, 60)) * 3, int(rng.integers(1, 40)) * 2, int(rng.integers(0, 9))) for _ in range(900)]
