@@ -57,6 +57,7 @@ SIGNATURES = {
     'cc_knn_force_fallback': (c_int, [c_int]),
     'cc_knn_force_full_select': (c_int, [c_int]),
     'cc_knn_last_fallback_count': (c_int64, []),
+    'cc_duplicate_representatives': (c_int, [c_void_p, c_int64, c_void_p]),
     'cc_profile_enable': (c_int, [c_int]),
     'cc_profile_reset': (c_int, []),
     'cc_profile_get': (c_int, [c_int, POINTER(c_int64), POINTER(c_double), POINTER(c_double)]),

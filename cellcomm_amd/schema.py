@@ -28,6 +28,31 @@ def find_duplicate_ids(np_coords):
     return [members[uc] for uc in set(coords) if len(members[uc]) > 1]
 
 
+def find_duplicate_ids_gpu(np_coords):
+    """Same result as find_duplicate_ids with the grouping done on the GPU
+    (cc_duplicate_representatives): only the UNIQUE coordinates pass through Python, to reproduce
+    the reference's group order (iteration order of the set of coordinate tuples — inserting the
+    distinct tuples in first-occurrence order builds the same set as inserting all of them)."""
+    import ctypes  # noqa: F401
+    from . import _lib
+    coords = np.ascontiguousarray(np_coords, dtype=np.float32)
+    n = len(coords)
+    if n == 0:
+        return []
+    rep = np.empty(n, dtype=np.int32)
+    _lib.check(_lib.ensure_init().cc_duplicate_representatives(coords.ctypes.data, n, rep.ctypes.data))
+    firsts = np.nonzero(rep == np.arange(n))[0]                 # one row per distinct coordinate (or NaN row)
+    order = np.argsort(rep, kind='stable')
+    bounds = np.searchsorted(rep[order], firsts)
+    members = {int(f): (order[b:e] + 1).tolist()
+               for f, b, e in zip(firsts, bounds, np.append(bounds[1:], n)) if e - b > 1}
+    uniq = [(c[0], c[1], c[2]) for c in np.asarray(np_coords)[firsts]]
+    first_of = {}
+    for f, t in zip(firsts, uniq):
+        first_of.setdefault(t, int(f))
+    return [members[first_of[uc]] for uc in set(uniq) if first_of.get(uc) in members]
+
+
 def encits_document(enc_run_id, it, encodings, barcodes, knn=None):
     encodings = np.asarray(encodings)
     enc_shape = encodings.shape

@@ -137,6 +137,13 @@ int cc_knn_force_full_select(int on);
 /* Queries of the last cc_knn_* call that needed the float64 fallback scan. */
 int64_t cc_knn_last_fallback_count(void);
 
+/* ---- duplicate coordinates: the `ds` field of an encits document
+ *      (reference src/intercepts/db_recorder.py:113-117, O(N·U) there) ------------- */
+
+/* rep[i] = smallest row index j whose (x, y, z) equals row i's (float equality: -0 == +0,
+ * NaN equals nothing, so a NaN row is its own representative).  xyz is host float32 [n x 3]. */
+int cc_duplicate_representatives(const float *host_xyz, int64_t n, int32_t *host_rep);
+
 /* ---- profiling ---------------------------------------------------------- */
 
 #define CC_PROF_GATHER 0

@@ -60,3 +60,24 @@ def test_device_resident_csr(hip, oracle_built):
     assert abs(host.nnz / (700 * 3000) - 0.05) < 0.005
     enc = cc.HipEncoder(8, 3000, 'cont', seed=2)
     assert np.array_equal(enc.predict(m_dev), enc.predict(host))
+
+
+def test_duplicate_groups_on_gpu_equal_reference(hip):
+    # the `ds` field: GPU grouping + reference group order == oracle restatement of find_duplicate_ids
+    from oracle import schema_oracle as so
+    rng = np.random.default_rng(13)
+    enc = rng.integers(0, 5, (3000, 3)).astype(np.float32) / 4            # saturated lattice: many duplicates
+    enc[7] = [0.0, -0.0, 0.5]
+    enc[9] = [-0.0, 0.0, 0.5]                                              # -0.0 == +0.0
+    enc[11] = [np.nan, 0.25, 0.25]
+    enc[12] = [np.nan, 0.25, 0.25]                                         # NaN equals nothing
+    coords = np.multiply(enc, 255)
+    got = schema.find_duplicate_ids_gpu(coords)
+    assert got == so.find_duplicate_ids(coords)
+    assert got == schema.find_duplicate_ids(coords)
+    assert not any(12 in g or 13 in g for g in got) and any(8 in g and 10 in g for g in got)
+    big = np.multiply(rng.integers(0, 60, (100000, 3)).astype(np.float32) / 59, 255)
+    assert schema.find_duplicate_ids_gpu(big) == schema.find_duplicate_ids(big)
+    assert schema.find_duplicate_ids_gpu(np.zeros((0, 3), dtype=np.float32)) == []
+    uniq = np.multiply(rng.random((5000, 3), dtype=np.float32), 255)
+    assert schema.find_duplicate_ids_gpu(uniq) == []
