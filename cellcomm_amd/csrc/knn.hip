@@ -448,10 +448,16 @@ __device__ __forceinline__ void collect_step(const float4 (&a)[NG], const float4
 // LDS (4 blocks = 128 candidates per stage, double buffered, one barrier per stage) so that one
 // global read of a panel feeds all four waves: at one wave per panel read the kernel needs
 // 16 B/clk/CU of panel traffic and is fabric-bound once the candidate set outgrows the L2s.
-constexpr int COL_CB = 4;  // candidate blocks per LDS stage (COL_CB·64 = 256 float4 per group = one per thread)
+#ifndef CC_KNN_COL_CB
+#define CC_KNN_COL_CB 2
+#endif
+#ifndef CC_KNN_COL_MINW
+#define CC_KNN_COL_MINW 2
+#endif
+constexpr int COL_CB = CC_KNN_COL_CB;  // candidate blocks per LDS stage
 
 template <int NG>
-__global__ __launch_bounds__(256, 2) void knn_collect_kernel(
+__global__ __launch_bounds__(256, CC_KNN_COL_MINW) void knn_collect_kernel(
     const float4 *__restrict__ P, const float *__restrict__ norms, const float *__restrict__ x,
     const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
     const float *__restrict__ T, int S, int64_t NBs, int cap, u64 *__restrict__ buf, int *__restrict__ cursor) {
@@ -514,22 +520,24 @@ __global__ __launch_bounds__(256, 2) void knn_collect_kernel(
   const f32x4 *Pv = reinterpret_cast<const f32x4 *>(P);
   f32x4 *stage_v = reinterpret_cast<f32x4 *>(smem);
   // staged float4 number f = tid + 256·i of a stage lies in block cb = f / (NG·64) of that stage
-  int s_cb[NG], s_off[NG];
+  constexpr int NS = (STAGE_F4 + 255) / 256;   // float4 staged per thread
+  int s_cb[NS], s_off[NS];
 #pragma unroll
-  for (int i = 0; i < NG; ++i) {
-    const int f = i * 256 + tid;
+  for (int i = 0; i < NS; ++i) {
+    int f = i * 256 + tid;
+    f = f < STAGE_F4 ? f : STAGE_F4 - 1;       // surplus threads of the last round duplicate the last float4
     s_cb[i] = f / (NG * 64);
     s_off[i] = f - s_cb[i] * (NG * 64);
   }
-  f32x4 rs[NG];
+  f32x4 rs[NS];
 #pragma unroll
-  for (int i = 0; i < NG; ++i) {
+  for (int i = 0; i < NS; ++i) {
     int64_t b = b_lo + s_cb[i];
     b = b < b_hi ? b : b_hi - 1;
     rs[i] = Pv[b * (NG * 64) + s_off[i]];
   }
 #pragma unroll
-  for (int i = 0; i < NG; ++i) stage_v[i * 256 + tid] = rs[i];
+  for (int i = 0; i < NS; ++i) stage_v[s_cb[i] * (NG * 64) + s_off[i]] = rs[i];
   __syncthreads();
 
   int cur = 0;
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(256, 2) void knn_collect_kernel(
     const bool more = st + 1 < nstages;
     if (more) {
 #pragma unroll
-      for (int i = 0; i < NG; ++i) {
+      for (int i = 0; i < NS; ++i) {
         int64_t b = b_lo + (st + 1) * COL_CB + s_cb[i];
         b = b < b_hi ? b : b_hi - 1;
         rs[i] = Pv[b * (NG * 64) + s_off[i]];
@@ -557,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void knn_collect_kernel(
     if (more) {
       f32x4 *dbuf = stage_v + (cur ^ 1) * STAGE_F4;  // last read in stage st-1: every wave is past that barrier
 #pragma unroll
-      for (int i = 0; i < NG; ++i) dbuf[i * 256 + tid] = rs[i];
+      for (int i = 0; i < NS; ++i) dbuf[s_cb[i] * (NG * 64) + s_off[i]] = rs[i];
     }
     __syncthreads();
     cur ^= 1;
@@ -878,7 +886,10 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   // m-th best of the sample (m = max(16, k)): the number of candidates below T is ~Gamma(m)·8, i.e.
   // 8m on average, >= k and <= 4·8m except with probability < 1e-5 per query; either miss only
   // sends that query to the float64 fallback.
-  const int SAMPLE = 8;
+#ifndef CC_KNN_SAMPLE
+#define CC_KNN_SAMPLE 8
+#endif
+  const int SAMPLE = CC_KNN_SAMPLE;
   const int m = k > 16 ? k : 16;
   const bool sampled = !g_force_route_a && NB >= 64 * SAMPLE && N >= (int64_t)64 * SAMPLE * m && k <= 50;
   const int col_cap = 4 * SAMPLE * m;   // collect buffer entries per query
@@ -925,7 +936,10 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
     const float *Tptr = nullptr;
     if (sampled) {
       // 1b-i: threshold from the sample (select with m-entry lists over every 8th block)
-      const int KPS = (int)round_up(m, 16), CAPS = KPS + 16;
+#ifndef CC_KNN_SAMPLE_SPARE
+#define CC_KNN_SAMPLE_SPARE 48
+#endif
+      const int KPS = (int)round_up(m, 16), CAPS = KPS + CC_KNN_SAMPLE_SPARE;
       if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS)))) return rc;
       if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q))) return rc;
       if ((rc = Tq.alloc(sizeof(float) * (size_t)n_q))) return rc;
