@@ -14,8 +14,9 @@
 // "multiply this A tile with W_hi and with W_lo", nterms = 1 "with W_hi only".  A 3-term input is
 // the two segments {A_hi, 2} and {A_lo, 1} over the same weight rows.
 //
-// Tile: 128 x 128 per 256-thread workgroup, 4 waves as 2 x 2, 64 x 64 per wave (64 accumulator
-// registers), K-step 64.  LDS: A [128][64+8] fp16 (the pad makes the 16-byte fragment reads
+// Tile: 256 x 128 per 256-thread workgroup, 4 waves as 2 x 2, 128 x 64 per wave (128 accumulator
+// registers: the A fragments are re-used by W_hi and W_lo and LDS traffic per MFMA halves against a
+// 64 x 64 wave tile, which is what bound the first version), K-step 64.  LDS: A [256][64+8] fp16 (the pad makes the 16-byte fragment reads
 // conflict-free), W_hi / W_lo tiles [8][128][8] fp16 — pre-packed so a lane's 8 consecutive k for
 // one column are one 16-byte read and a tile is 16 KiB contiguous in HBM.
 #include "common.h"
@@ -26,7 +27,15 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 
-constexpr int HB_M = 128, HB_N = 128, HB_K = 64;
+#ifndef CC_G16_WM
+#define CC_G16_WM 4          // 32-row MFMA tiles per wave along M: 2 -> 128 x 128 workgroup tile, 4 -> 256 x 128
+#endif
+#ifndef CC_G16_MINW
+#define CC_G16_MINW 2
+#endif
+constexpr int WM_T = CC_G16_WM;
+constexpr int HB_M = 64 * WM_T, HB_N = 128, HB_K = 64;
+constexpr int A_PASSES = HB_M / 32;                  // staging passes of 32 rows
 constexpr int H_LDS_A_STRIDE = HB_K + 8;             // halfs
 constexpr int H_THREADS = 256;
 constexpr int H_TILE_W = (HB_K / 8) * HB_N;          // 16-byte units per W tile (1024 = 16 KiB)
@@ -44,7 +53,7 @@ __device__ __forceinline__ float sigmoid16_(float z) { return 1.0f / (1.0f + exp
 
 // OUT_MODE 0: C fp32 [M x ldc];  1: C_hi (and C_lo when split) fp16 planes [M x ldc]
 template <int OUT_MODE>
-__global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64_t M, const f32x4 *__restrict__ Wp,
+__global__ __launch_bounds__(H_THREADS, CC_G16_MINW) void gemm16_kernel(Segs16 segs, int64_t M, const f32x4 *__restrict__ Wp,
                                                               const float *__restrict__ bias, float inv_scale,
                                                               int KTW, int N, int MT, int NT, void *__restrict__ C,
                                                               void *__restrict__ C_lo, int64_t ldc, int act) {
@@ -72,16 +81,16 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64
 
   // A staging: 128 rows x 8 chunks of 16 B; thread -> (row = tid/8 + 32p, chunk = tid%8)
   const int a_row = tid >> 3, a_ch = tid & 7;
-  int a_lr[4];
+  int a_lr[A_PASSES];
 #pragma unroll
-  for (int p = 0; p < 4; ++p) {
+  for (int p = 0; p < A_PASSES; ++p) {
     const int64_t gr = m0 + a_row + 32 * p;
     a_lr[p] = (int)((gr < M ? gr : M - 1) - m0);
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[WM_T][2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WM_T; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -89,8 +98,8 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64
 
   const f32x4 *Wn = Wp + (int64_t)n_tile * KTW * (2 * H_TILE_W) + tid;   // [n_tile][kt][hi|lo][1024]
 
-  f32x4 ra[4], rh[4], rl[4];
-  const _Float16 *a_lds = As + (wm * 64 + r) * H_LDS_A_STRIDE + 8 * h;
+  f32x4 ra[A_PASSES], rh[4], rl[4];
+  const _Float16 *a_lds = As + (wm * 32 * WM_T + r) * H_LDS_A_STRIDE + 8 * h;
   const f32x4 *bh_lds = Bh + h * HB_N + wn * 64 + r;
   const f32x4 *bl_lds = Bl + h * HB_N + wn * 64 + r;
 
@@ -98,15 +107,15 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64
     const Seg16 sg = segs.s[si];
     if (sg.KT == 0) continue;
     const bool two = sg.nterms == 2;   // uniform
-    const _Float16 *pa[4];
+    const _Float16 *pa[A_PASSES];
 #pragma unroll
-    for (int p = 0; p < 4; ++p) pa[p] = sg.A + (m0 + a_lr[p]) * sg.lda + 8 * a_ch;
+    for (int p = 0; p < A_PASSES; ++p) pa[p] = sg.A + (m0 + a_lr[p]) * sg.lda + 8 * a_ch;
     const f32x4 *wt = Wn + (int64_t)sg.wkt0 * (2 * H_TILE_W);
 
     // prologue of the segment: stage k-tile 0
     __syncthreads();   // previous segment's last tile fully consumed
 #pragma unroll
-    for (int p = 0; p < 4; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += HB_K; }
+    for (int p = 0; p < A_PASSES; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += HB_K; }
 #pragma unroll
     for (int p = 0; p < 4; ++p) rh[p] = wt[p * H_THREADS];
     if (two) {
@@ -117,7 +126,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64
     {
       _Float16 *aw = As + a_row * H_LDS_A_STRIDE + 8 * a_ch;
 #pragma unroll
-      for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(aw + p * 32 * H_LDS_A_STRIDE) = ra[p];
+      for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(aw + p * 32 * H_LDS_A_STRIDE) = ra[p];
 #pragma unroll
       for (int p = 0; p < 4; ++p) Bh[tid + p * H_THREADS] = rh[p];
       if (two) {
@@ -131,7 +140,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64
       const bool more = kt + 1 < sg.KT;
       if (more) {
 #pragma unroll
-        for (int p = 0; p < 4; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += HB_K; }
+        for (int p = 0; p < A_PASSES; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += HB_K; }
 #pragma unroll
         for (int p = 0; p < 4; ++p) rh[p] = wt[p * H_THREADS];
         if (two) {
@@ -144,14 +153,14 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int t = 0; t < HB_K / 16; ++t) {
-        h8 a[2], bh[2];
+        h8 a[WM_T], bh[2];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < WM_T; ++mt)
           a[mt] = *reinterpret_cast<const h8 *>(a_lds + mt * 32 * H_LDS_A_STRIDE + 16 * t);
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) bh[nt] = __builtin_bit_cast(h8, bh_lds[2 * t * HB_N + nt * 32]);
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+        for (int mt = 0; mt < WM_T; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt)
             acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bh[nt], acc[mt][nt], 0, 0, 0);
@@ -160,7 +169,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) bl[nt] = __builtin_bit_cast(h8, bl_lds[2 * t * HB_N + nt * 32]);
 #pragma unroll
-          for (int mt = 0; mt < 2; ++mt)
+          for (int mt = 0; mt < WM_T; ++mt)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
               acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bl[nt], acc[mt][nt], 0, 0, 0);
@@ -171,7 +180,7 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64
       if (more) {
         _Float16 *aw = As + a_row * H_LDS_A_STRIDE + 8 * a_ch;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) *reinterpret_cast<f32x4 *>(aw + p * 32 * H_LDS_A_STRIDE) = ra[p];
+        for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(aw + p * 32 * H_LDS_A_STRIDE) = ra[p];
 #pragma unroll
         for (int p = 0; p < 4; ++p) Bh[tid + p * H_THREADS] = rh[p];
         if (two) {
@@ -190,10 +199,10 @@ __global__ __launch_bounds__(H_THREADS, 2) void gemm16_kernel(Segs16 segs, int64
     const bool col_ok = col < N;
     const float bcol = col_ok ? bias[col] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < WM_T; ++mt) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int64_t row = m0 + wm * 32 * WM_T + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (col_ok && row < M) {
           float z = acc[mt][nt][e] * inv_scale + bcol;
           z = (act == ACT_SIGMOID) ? sigmoid16_(z) : z;
