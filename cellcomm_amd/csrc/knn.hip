@@ -883,14 +883,14 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
 
   // Route 1b (sampled threshold + collect) for large candidate sets and moderate k; route 1a
   // (full select with running threshold) otherwise.  Sample = every 8th candidate block, T = the
-  // m-th best of the sample (m = max(16, k)): the number of candidates below T is ~Gamma(m)·8, i.e.
-  // 8m on average, >= k and <= 4·8m except with probability < 1e-5 per query; either miss only
+  // m-th best of the sample (m = max(16, 3k/8)): the number of candidates below T is ~Gamma(m)·8, i.e.
+  // 8m >= 3k on average, >= k and <= 4·8m except with probability < 1e-4 per query; either miss only
   // sends that query to the float64 fallback.
 #ifndef CC_KNN_SAMPLE
 #define CC_KNN_SAMPLE 8
 #endif
   const int SAMPLE = CC_KNN_SAMPLE;
-  const int m = k > 16 ? k : 16;
+  const int m = (3 * k + 7) / 8 > 16 ? (3 * k + 7) / 8 : 16;
   const bool sampled = !g_force_route_a && NB >= 64 * SAMPLE && N >= (int64_t)64 * SAMPLE * m && k <= 50;
   const int col_cap = 4 * SAMPLE * m;   // collect buffer entries per query
 
