@@ -32,7 +32,9 @@ def find_duplicate_ids_gpu(np_coords):
     """Same result as find_duplicate_ids with the grouping done on the GPU
     (cc_duplicate_representatives): only the UNIQUE coordinates pass through Python, to reproduce
     the reference's group order (iteration order of the set of coordinate tuples — inserting the
-    distinct tuples in first-occurrence order builds the same set as inserting all of them)."""
+    distinct tuples in first-occurrence order builds the same set as inserting all of them; with NaN
+    coordinates that order is not reproducible even by the reference itself, CPython hashes a NaN by
+    object identity)."""
     import ctypes  # noqa: F401
     from . import _lib
     coords = np.ascontiguousarray(np_coords, dtype=np.float32)

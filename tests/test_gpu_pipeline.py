@@ -69,15 +69,49 @@ def test_duplicate_groups_on_gpu_equal_reference(hip):
     enc = rng.integers(0, 5, (3000, 3)).astype(np.float32) / 4            # saturated lattice: many duplicates
     enc[7] = [0.0, -0.0, 0.5]
     enc[9] = [-0.0, 0.0, 0.5]                                              # -0.0 == +0.0
-    enc[11] = [np.nan, 0.25, 0.25]
-    enc[12] = [np.nan, 0.25, 0.25]                                         # NaN equals nothing
     coords = np.multiply(enc, 255)
     got = schema.find_duplicate_ids_gpu(coords)
     assert got == so.find_duplicate_ids(coords)
     assert got == schema.find_duplicate_ids(coords)
-    assert not any(12 in g or 13 in g for g in got) and any(8 in g and 10 in g for g in got)
+    assert any(8 in g and 10 in g for g in got)
+    # NaN equals nothing (and CPython >= 3.10 hashes a NaN by object identity, so with NaN rows the
+    # reference's own group ORDER changes from run to run): contents only
+    enc[11] = [np.nan, 0.25, 0.25]
+    enc[12] = [np.nan, 0.25, 0.25]
+    coords = np.multiply(enc, 255)
+    got = schema.find_duplicate_ids_gpu(coords)
+    assert sorted(got) == sorted(so.find_duplicate_ids(coords))
+    assert not any(12 in g or 13 in g for g in got)
     big = np.multiply(rng.integers(0, 60, (100000, 3)).astype(np.float32) / 59, 255)
     assert schema.find_duplicate_ids_gpu(big) == schema.find_duplicate_ids(big)
     assert schema.find_duplicate_ids_gpu(np.zeros((0, 3), dtype=np.float32)) == []
     uniq = np.multiply(rng.random((5000, 3), dtype=np.float32), 255)
     assert schema.find_duplicate_ids_gpu(uniq) == []
+
+
+def test_integration_md_stub_runs_as_written(hip):
+    # the ctypes stub printed in INTEGRATION.md, executed verbatim against the built library
+    import re
+    from conftest import ROOT
+    from cellcomm_amd import _lib
+    text = open(f'{ROOT}/INTEGRATION.md').read()
+    code = re.search(r'```python\n(import ctypes, numpy as np.*?)```', text, flags=re.S).group(1)
+    code = code.replace('/path/to/libcellcomm_hip.so', _lib.lib_path())
+    ns = {}
+    exec(compile(code, 'INTEGRATION.md', 'exec'), ns)
+    g, e = 300, 6
+    ws = eo.glorot_weights('cont', e, g, seed=3, randomize_bn=True, bias_scale=0.1)
+
+    class KerasLike:                                   # what the reference's _build_encoder returns, as far as the stub cares
+        def get_weights(self):
+            return ws
+
+    stub = ns['hip_cont_encoder_factory'](lambda es, gs: KerasLike())(e, g)
+    x = np.random.default_rng(0).integers(0, 5, (17, g)).astype(np.float32)
+    out = stub.predict(x.tolist())
+    truth = eo.forward('cont', ws, x)
+    assert out.shape == (17, e) and np.max(np.abs(out - truth) / np.abs(truth)) <= 1e-4
+    assert len(stub.layers) == 5 and len(stub.layers[0].get_weights()) == 2
+    net = cc.BasicBiGan(e, g, lambda a, b: cc.bigan.AbsentComponent('g', a, b), lambda a, b: stub,
+                        lambda a, b: cc.bigan.AbsentComponent('d', a, b))
+    assert np.array_equal(net.encoding_prediction(x), out)
