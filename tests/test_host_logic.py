@@ -253,3 +253,27 @@ def test_shard_bounds_partition(n, world):
         assert b == c and a <= b and c <= d
     per = -(-n // world)
     assert all(hi - lo == per for lo, hi in blocks[:-1] if hi < n)
+
+
+def test_native_parser_random_files_equal_pivot(tmp_path):
+    # seeded sweep: ragged ids, duplicates, zeros, negative and float values, shuffled order
+    rng = np.random.default_rng(77)
+    for case in range(25):
+        n_trip = int(rng.integers(1, 400))
+        genes = rng.integers(-5, 60, n_trip) * int(rng.integers(1, 1000))
+        cells = rng.integers(0, 30, n_trip) + int(rng.integers(0, 10 ** 9))
+        if case % 3 == 0:
+            vals = rng.integers(-3, 50, n_trip).astype(object)
+        else:
+            vals = np.round(rng.standard_normal(n_trip) * 10, int(rng.integers(0, 4))).astype(object)
+        path = tmp_path / f'r{case}.mtx'
+        sep = [' ', '\\t', '  '][case % 3]
+        with open(path, 'w') as f:
+            f.write('x\\ny\\nz\\n')
+            for g, c, v in zip(genes, cells, vals):
+                f.write(f'{g}{sep}{c}{sep}{v}\\n')
+        want = lo.load_matrix(path)
+        got = matrix.load_matrix(path)
+        assert got.shape == want.shape, case
+        assert np.array_equal(got.index, want.index.to_numpy()) and np.array_equal(got.columns, want.columns.to_numpy())
+        assert np.array_equal(got.to_dense(np.float64), want.to_numpy().astype(np.float32).astype(np.float64)), case
