@@ -56,6 +56,7 @@ SIGNATURES = {
     'cc_knn_l2_dev': (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
     'cc_knn_force_fallback': (c_int, [c_int]),
     'cc_knn_force_full_select': (c_int, [c_int]),
+    'cc_knn_use_fp16_collect': (c_int, [c_int]),
     'cc_knn_last_fallback_count': (c_int64, []),
     'cc_duplicate_representatives': (c_int, [c_void_p, c_int64, c_void_p]),
     'cc_profile_enable': (c_int, [c_int]),

@@ -41,6 +41,7 @@ using u64 = unsigned long long;
 
 static bool g_force_fallback = false;
 static bool g_force_route_a = false;  // test hook: always take the full-select route
+static bool g_use_fp16_collect = true; // stage 1b collect on the fp16 matrix cores when the data's scale allows
 static int64_t g_last_fallback = 0;
 
 __device__ __forceinline__ unsigned f32_to_ordered(float f) {
@@ -81,13 +82,16 @@ __global__ void knn_norm_kernel(const float *__restrict__ x, const float *__rest
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= N) return;
   double s = 0.0;
+  float amax = 0.f;
   for (int t = 0; t < d; ++t) {
-    double v = (double)centred(x[i * d + t], mu[t]);
-    s += v * v;
+    const float y = centred(x[i * d + t], mu[t]);
+    amax = fmaxf(amax, fabsf(y));
+    s += (double)y * (double)y;
   }
   const float f = (float)s;
   norms[i] = f;
-  atomicMax(maxnorm_bits, __float_as_uint(f));  // non-negative floats order as uints
+  atomicMax(maxnorm_bits, __float_as_uint(f));      // non-negative floats order as uints
+  atomicMax(maxnorm_bits + 1, __float_as_uint(amax));  // largest |centred coordinate| (scale of the fp16 panels)
 }
 
 // ---- candidate packing ---------------------------------------------------------
@@ -573,6 +577,244 @@ __global__ __launch_bounds__(256, CC_KNN_COL_MINW) void knn_collect_kernel(
   wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
 }
 
+// ---- stage 1b on the fp16 matrix cores ------------------------------------------------------------
+// The collect pass only needs approximate distances with a KNOWN error bound (the certificate of
+// stage 2 absorbs it), so it can run on v_mfma_f32_32x32x16_f16 at 16x the fp32 MFMA rate with every
+// centred coordinate split as y·s = y_hi + y_lo (two fp16 values, s a power of two putting max|y·s| in
+// [2^6, 2^7)):  −2 q·c ≈ qh·ch + qh·cl + ql·ch (3·ND MFMAs, ND = ceil(d/16)); the two norms ride in
+// one extra K-step of the hi·hi product as three fp16 pieces each (33 bits).  13 MFMAs x 32 cycles per
+// 32 x 32 tile at d = 64 instead of 36 x 64.
+using h8 = __attribute__((ext_vector_type(8))) _Float16;
+
+__device__ __forceinline__ void split3(float v, _Float16 *a, _Float16 *b, _Float16 *c) {
+  *a = (_Float16)v;
+  const float r1 = v - (float)*a;
+  *b = (_Float16)r1;
+  *c = (_Float16)(r1 - (float)*b);
+}
+
+// one 16-byte unit (8 halfs) of operand data for row `i` of x, K-step t, lane half h:
+//   t < ND          hi parts of (fac · y[16t + 8h + j]),  j = 0..7
+//   t == ND         norm step: h == 0 -> {n_a, n_b, n_c, 256, 256, 256, 0, 0} (candidate side) or
+//                                        {256, 256, 256, n_a, n_b, n_c, 0, 0} (query side); h == 1 -> 0
+//   t > ND          lo parts of K-step t − ND − 1
+__device__ __forceinline__ h8 panel16_unit(const float *__restrict__ x, const float *__restrict__ mu,
+                                           const float *__restrict__ norms, int64_t i, bool valid, int d, int ND, int t,
+                                           int h, float fac, float s2_over_256, bool query_side) {
+  h8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.f;
+  if (!valid) return o;
+  if (t == ND) {
+    if (h == 0) {
+      _Float16 a, b, c;
+      split3(norms[i] * s2_over_256, &a, &b, &c);
+      const _Float16 k256 = (_Float16)256.f;
+      if (query_side) { o[0] = k256; o[1] = k256; o[2] = k256; o[3] = a; o[4] = b; o[5] = c; }
+      else { o[0] = a; o[1] = b; o[2] = c; o[3] = k256; o[4] = k256; o[5] = k256; }
+    }
+    return o;
+  }
+  const bool lo = t > ND;
+  const int kt = lo ? t - ND - 1 : t;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int k = 16 * kt + 8 * h + j;
+    if (k < d) {
+      const float v = fac * centred(x[i * d + k], mu[k]);
+      const _Float16 hi = (_Float16)v;
+      o[j] = lo ? (_Float16)(v - (float)hi) : hi;
+    }
+  }
+  return o;
+}
+
+// P16[((b·(2ND+1) + t)·64 + lane)] (16-byte units): candidate 32b + (lane&31), lane half = lane>>5
+__global__ void knn_pack16_kernel(const float *__restrict__ x, const float *__restrict__ mu,
+                                  const float *__restrict__ norms, int64_t N, int d, int ND, int64_t NB, float s,
+                                  h8 *__restrict__ P16) {
+  const int NT = 2 * ND + 1;
+  const int64_t total = NB * NT * 64;
+  const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f >= total) return;
+  const int lane = f & 63;
+  const int t = (int)((f >> 6) % NT);
+  const int64_t b = (f >> 6) / NT;
+  const int64_t cand = b * 32 + (lane & 31);
+  P16[f] = panel16_unit(x, mu, norms, cand, cand < N, d, ND, t, lane >> 5, s, s * s * (1.0f / 256.0f), false);
+}
+
+template <int ND>
+__device__ __forceinline__ void collect16_step(const h8 *__restrict__ sb, const h8 (&bqh)[ND + 1], const h8 (&bql)[ND],
+                                               int64_t b, int64_t NB, int64_t self_blk, int self_e, unsigned tail_vm,
+                                               float Ts, float inv_s2, WaveBuf &wb, u64 *__restrict__ buf,
+                                               int *__restrict__ cursor, int64_t q0, int64_t n_q, int cap, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+  h8 ah[ND + 1], al[ND];
+#pragma unroll
+  for (int t = 0; t <= ND; ++t) ah[t] = sb[t * 64 + lane];
+#pragma unroll
+  for (int t = 0; t < ND; ++t) al[t] = sb[(ND + 1 + t) * 64 + lane];
+#pragma unroll
+  for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bqh[t], acc, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bql[t], acc, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bqh[t], acc, 0, 0, 0);
+  if (__any(b == self_blk) || b == NB - 1) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const bool kill = (b == self_blk && e == self_e) || (b == NB - 1 && !((tail_vm >> e) & 1u));
+      acc[e] = kill ? __builtin_nanf("") : acc[e];
+    }
+  }
+  const int c_l = count_regs<0, 16>(acc, Ts);
+  if (!__any(c_l)) return;
+  const unsigned cbase = (unsigned)(b * 32) + 4 * h;
+  int incl = c_l;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int up = __shfl_up(incl, o);
+    if (lane >= o) incl += up;
+  }
+  const int total = __builtin_amdgcn_readlane(incl, 63);
+  if (total > COL_WB) {
+    const int64_t ql = q0 + r;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      if (acc[e] <= Ts && ql < n_q) {
+        const int pos = atomicAdd(cursor + ql, 1);
+        if (pos < cap)
+          buf[ql * cap + pos] = ((u64)f32_to_ordered(acc[e] * inv_s2) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
+      }
+    }
+    return;
+  }
+  if (wb.n + total > COL_WB) wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
+  int pos = wb.n + incl - c_l;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const bool pass = acc[e] <= Ts;
+    if (__ballot(pass)) {
+      if (pass) {
+        wb.key[pos] = ((u64)f32_to_ordered(acc[e] * inv_s2) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
+        wb.qr[pos] = r;
+        ++pos;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  wb.n += total;
+}
+
+constexpr int C16_CB = 4;  // candidate blocks per LDS stage
+
+template <int ND>
+__global__ __launch_bounds__(256, 2) void knn_collect16_kernel(
+    const h8 *__restrict__ P16, const float *__restrict__ norms, const float *__restrict__ x,
+    const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
+    const float *__restrict__ T, float s, int S, int64_t NBs, int cap, u64 *__restrict__ buf,
+    int *__restrict__ cursor) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = 2 * ND + 1;
+  constexpr int BLK_U = NT * 64;             // 16-byte units per candidate block
+  constexpr int STAGE_U = C16_CB * BLK_U;
+  h8 *stage = reinterpret_cast<h8 *>(smem);  // [2][STAGE_U], then the 4 parking buffers
+
+  const int64_t tile = blockIdx.x / S;
+  const int split = blockIdx.x % S;
+  const int64_t b_lo = split * NBs;
+  const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t ql = tile * 128 + wave * 32 + r;
+  const bool qvalid = ql < n_q;
+  const int64_t q = q_begin + ql;
+  const float s2 = s * s, inv_s2 = 1.0f / s2;
+
+  h8 bqh[ND + 1], bql[ND];
+#pragma unroll
+  for (int t = 0; t <= ND; ++t) bqh[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
+#pragma unroll
+  for (int t = 0; t < ND; ++t) bql[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, ND + 1 + t, h, -2.0f * s, 0.f, true);
+  const float Ts = qvalid ? T[ql] * s2 : -INFINITY;
+  const int64_t q0 = tile * 128 + wave * 32;
+  WaveBuf wb;
+  wb.key = reinterpret_cast<u64 *>(smem + sizeof(h8) * 2 * STAGE_U) + wave * COL_WB;
+  wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * 2 * STAGE_U + sizeof(u64) * 4 * COL_WB) + wave * COL_WB;
+  wb.n = 0;
+
+  int64_t self_blk = -1;
+  int self_e = -1;
+  if (qvalid && !include_self) {
+    const int row = (int)(q & 31);
+    if (((row >> 2) & 1) == h) {
+      self_blk = q >> 5;
+      self_e = (row & 3) | ((row >> 3) << 2);
+    }
+  }
+  unsigned tail_vm = 0xffffu;
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
+
+  const int64_t nstages = (b_hi - b_lo + C16_CB - 1) / C16_CB;
+  const f32x4 *Pv = reinterpret_cast<const f32x4 *>(P16);
+  f32x4 *stage_v = reinterpret_cast<f32x4 *>(smem);
+  constexpr int NS = (STAGE_U + 255) / 256;
+  int s_cb[NS], s_off[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    int f = i * 256 + tid;
+    f = f < STAGE_U ? f : STAGE_U - 1;
+    s_cb[i] = f / BLK_U;
+    s_off[i] = f - s_cb[i] * BLK_U;
+  }
+  f32x4 rs[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    int64_t b = b_lo + s_cb[i];
+    b = b < b_hi ? b : b_hi - 1;
+    rs[i] = Pv[b * BLK_U + s_off[i]];
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) stage_v[s_cb[i] * BLK_U + s_off[i]] = rs[i];
+  __syncthreads();
+
+  int cur = 0;
+  for (int64_t st = 0; st < nstages; ++st) {
+    const bool more = st + 1 < nstages;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        int64_t b = b_lo + (st + 1) * C16_CB + s_cb[i];
+        b = b < b_hi ? b : b_hi - 1;
+        rs[i] = Pv[b * BLK_U + s_off[i]];
+      }
+    }
+    const h8 *sbuf = stage + cur * STAGE_U;
+#pragma unroll
+    for (int cb = 0; cb < C16_CB; ++cb) {
+      const int64_t b = b_lo + st * C16_CB + cb;
+      if (b < b_hi)
+        collect16_step<ND>(sbuf + cb * BLK_U, bqh, bql, b, NB, self_blk, self_e, tail_vm, Ts, inv_s2, wb, buf, cursor, q0,
+                           n_q, cap, lane);
+    }
+    if (more) {
+      f32x4 *dbuf = stage_v + (cur ^ 1) * STAGE_U;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) dbuf[s_cb[i] * BLK_U + s_off[i]] = rs[i];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
+}
+
 // sample threshold: T[q] = approximate distance of the m-th best sampled candidate (+inf if fewer)
 __global__ void knn_threshold_kernel(const u64 *__restrict__ skeys, const int *__restrict__ scnt, int64_t n_q,
                                      int KPS, int m, float *__restrict__ T) {
@@ -847,6 +1089,29 @@ static int run_collect(int NG, const SelectArgs &a, const float *T, int S, int64
   return CC_OK;
 }
 
+static int run_collect16(int ND, const h8 *P16, const SelectArgs &a, const float *T, float s, int S, int64_t NBs,
+                         int cap, u64 *buf, int *cursor) {
+  const int64_t nwg = ceil_div(a.n_q, 128) * S;
+#define CC_C16(NDV)                                                                                           \
+  case NDV: {                                                                                                 \
+    const size_t lds = sizeof(h8) * 2 * C16_CB * (2 * NDV + 1) * 64 + (sizeof(u64) + sizeof(int)) * 4 * COL_WB; \
+    if (lds > 64 * 1024)                                                                                      \
+      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_collect16_kernel<NDV>),                  \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+    hipLaunchKernelGGL(knn_collect16_kernel<NDV>, dim3((unsigned)nwg), dim3(256), lds, stream(), P16, a.norms, \
+                       a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, NBs, cap, buf,   \
+                       cursor);                                                                               \
+    break;                                                                                                    \
+  }
+  switch (ND) {
+    CC_C16(1) CC_C16(2) CC_C16(4) CC_C16(8)
+    default: CC_REQUIRE(false, "knn: no fp16 collect kernel for ND=%d", ND);
+  }
+#undef CC_C16
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
 // split the NB candidate blocks into S contiguous ranges of NBs blocks (last may be short)
 static void make_splits(int64_t NB, int want, int *S, int64_t *NBs) {
   int s = want < 1 ? 1 : want;
@@ -894,8 +1159,8 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   const bool sampled = !g_force_route_a && NB >= 64 * SAMPLE && N >= (int64_t)64 * SAMPLE * m && k <= 50;
   const int col_cap = 4 * SAMPLE * m;   // collect buffer entries per query
 
-  static DevBuf P, norms, maxn, keys, cnts, bound, skeys, scnts, Tq, cbuf, ccur, oidx, odist, nflag, flagged, bnd_d,
-      bnd_i, partial, mu;
+  static DevBuf P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
+      bnd_d, bnd_i, partial, mu;
   int rc;
   if ((rc = P.alloc(sizeof(float4) * (size_t)(NB * NG * 64)))) return rc;
   if ((rc = norms.alloc(sizeof(float) * (size_t)N))) return rc;
@@ -929,6 +1194,11 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
     CC_HIP(hipGetLastError());
   }
   const SelectArgs sa{P.as<float4>(), norms.as<float>(), d_x, mu.as<float>(), N, d, NB, q_begin, n_q, include_self};
+  // fp32 error bound of stage 1 relative to (‖q−μ‖² + ‖c−μ‖²), u = 2^-24:
+  //   (2(d+2)+1)·u  d+2 fma terms on |terms| summing to <= 2(‖q‖²+‖c‖²), norms rounded to fp32
+  // + 4(1+3u)·u     rounding of the centred coordinates fl(x−μ)
+  // < (2d+10)·u; twice that is used.
+  double eps_coef = (4.0 * (double)(d + 4) + 8.0) * 5.9604644775390625e-08;
   {
     ProfScope prof(CC_PROF_KNN_SELECT, 2.0 * (double)n_q * (double)N * (double)d);
     int S = 1, lcap = KP;
@@ -951,7 +1221,40 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
       if ((rc = cbuf.alloc(sizeof(u64) * (size_t)n_q * (size_t)col_cap))) return rc;
       if ((rc = ccur.alloc(sizeof(int) * (size_t)n_q))) return rc;
       CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
-      if ((rc = run_collect(NG, sa, Tq.as<float>(), S, NBs, col_cap, cbuf.as<u64>(), ccur.as<int>()))) return rc;
+      // collect on the fp16 matrix cores when the centred data's scale keeps s, s² and the scaled
+      // norms well inside the fp32/fp16 ranges; otherwise on the fp32 ones
+      int ND16 = 0;
+      for (int o : {1, 2, 4, 8})
+        if (16 * o >= d) { ND16 = o; break; }
+      float scale16 = 0.f;
+      if (g_use_fp16_collect && ND16) {
+        unsigned h_max[2] = {0, 0};
+        CC_HIP(hipMemcpyAsync(h_max, maxn.p, sizeof h_max, hipMemcpyDeviceToHost, stream()));
+        CC_HIP(hipStreamSynchronize(stream()));
+        float amax;
+        memcpy(&amax, &h_max[1], sizeof amax);
+        int e = 0;
+        if (std::isfinite(amax) && amax > 0.f) {
+          (void)frexpf(amax, &e);
+          if (e > -30 && e < 30) scale16 = ldexpf(1.f, 7 - e);   // max|y|·s in [2^6, 2^7)
+        }
+      }
+      if (scale16 > 0.f) {
+        const int64_t units = NB * (2 * ND16 + 1) * 64;
+        if ((rc = P16.alloc(sizeof(h8) * (size_t)units))) return rc;
+        hipLaunchKernelGGL(knn_pack16_kernel, dim3((unsigned)ceil_div(units, 256)), dim3(256), 0, stream(), d_x,
+                           mu.as<float>(), norms.as<float>(), N, d, ND16, NB, scale16, P16.as<h8>());
+        if ((rc = run_collect16(ND16, P16.as<h8>(), sa, Tq.as<float>(), scale16, S, NBs, col_cap, cbuf.as<u64>(),
+                                ccur.as<int>())))
+          return rc;
+        // error bound of the fp16-split tile, relative to (‖q−μ‖² + ‖c−μ‖²), u = 2^-24:
+        //   16(3·ND+1) product terms accumulated in fp32 on |terms| summing to <= 3(‖q‖²+‖c‖²)
+        // + 12u  dropped lo·lo products and the 22-bit split of each coordinate
+        // + 4u   rounding of the centred coordinates;  twice the sum is used.
+        eps_coef = 2.0 * (3.0 * 16.0 * (3.0 * ND16 + 1.0) + 16.0) * 5.9604644775390625e-08;
+      } else if ((rc = run_collect(NG, sa, Tq.as<float>(), S, NBs, col_cap, cbuf.as<u64>(), ccur.as<int>()))) {
+        return rc;
+      }
       S = 1;
       lcap = col_cap;
       Tptr = Tq.as<float>();
@@ -978,11 +1281,6 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
     }
     CC_HIP(hipGetLastError());
   }
-  // fp32 error bound of stage 1 relative to (‖q−μ‖² + ‖c−μ‖²), u = 2^-24:
-  //   (2(d+2)+1)·u  d+2 fma terms on |terms| summing to <= 2(‖q‖²+‖c‖²), norms rounded to fp32
-  // + 4(1+3u)·u     rounding of the centred coordinates fl(x−μ)
-  // < (2d+10)·u; twice that is used.
-  const double eps_coef = (4.0 * (double)(d + 4) + 8.0) * 5.9604644775390625e-08;
   {
     const size_t per_wave = (sizeof(double) * (size_t)(d + KP) + sizeof(int) * (size_t)KP + 15) / 16 * 16;
     ProfScope prof(CC_PROF_KNN_RERANK, 3.0 * (double)n_q * (double)KP * (double)d);
@@ -1017,6 +1315,10 @@ extern "C" int cc_knn_force_fallback(int on) {
   return CC_OK;
 }
 extern "C" int64_t cc_knn_last_fallback_count(void) { return cc::g_last_fallback; }
+extern "C" int cc_knn_use_fp16_collect(int on) {
+  cc::g_use_fp16_collect = on != 0;
+  return CC_OK;
+}
 extern "C" int cc_knn_force_full_select(int on) {
   cc::g_force_route_a = on != 0;
   return CC_OK;

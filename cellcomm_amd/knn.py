@@ -56,3 +56,8 @@ def force_fallback(on):
 def force_full_select(on):
     """Test hook: route every call through the full running-threshold select (stage 1a)."""
     _lib.check(_lib.lib().cc_knn_force_full_select(1 if on else 0))
+
+
+def use_fp16_collect(on):
+    """Stage 1b collect pass on the fp16 (default) or fp32 matrix cores; same results, different speed."""
+    _lib.check(_lib.lib().cc_knn_use_fp16_collect(1 if on else 0))

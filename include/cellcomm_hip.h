@@ -132,6 +132,9 @@ int cc_knn_l2_dev(const float *dev_x, int64_t n_total, int d, int64_t q_begin, i
                   int k, int include_self, int32_t *host_idx, float *host_dist);
 /* Test hook: route every query through the float64 fallback scan. */
 int cc_knn_force_fallback(int on);
+/* Stage 1b collect pass on the fp16 matrix cores (default on) or the fp32 ones; results are
+ * identical either way (stage 2 certifies or falls back), only speed differs. */
+int cc_knn_use_fp16_collect(int on);
 /* Test hook: disable the sampled-threshold route of stage 1 (always full select). */
 int cc_knn_force_full_select(int on);
 /* Queries of the last cc_knn_* call that needed the float64 fallback scan. */

@@ -108,6 +108,12 @@ def test_sampled_threshold_route(hip, oracle_built, n, d, k, include_self):
     finally:
         hipknn.force_full_select(False)
     assert np.array_equal(idx, idx_a) and np.array_equal(dist, dist_a)
+    hipknn.use_fp16_collect(False)                                            # collect pass on the fp32 matrix cores
+    try:
+        idx_b, dist_b = cc.knn_graph(x, k, include_self)
+    finally:
+        hipknn.use_fp16_collect(True)
+    assert np.array_equal(idx, idx_b) and np.array_equal(dist, dist_b)
     assert n_fb < n // 50                                                       # the threshold rarely misses
 
 
