@@ -41,6 +41,12 @@ SIGNATURES = {
     'cc_encoder_set_weights': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64]),
     'cc_encoder_set_batch': (c_int, [c_void_p, c_int64]),
     'cc_encoder_fp32_fallback_passes': (c_int64, [c_void_p]),
+    'cc_generator_create': (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    'cc_generator_free': (None, [c_void_p]),
+    'cc_generator_num_weights': (c_int, [c_void_p]),
+    'cc_generator_weight_shape': (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64)]),
+    'cc_generator_set_weights': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64]),
+    'cc_generate_dense': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
     'cc_csr_upload': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_void_p)]),
     'cc_csr_wrap_device': (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, POINTER(c_void_p)]),
     'cc_csr_free': (None, [c_void_p]),

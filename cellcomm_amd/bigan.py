@@ -8,10 +8,11 @@ encoder and discriminator by calling the three factories with
 (:28-30, pinned by reference test/bigans_basic_test.py:25-31).  These classes keep
 that contract with a HIP encoder as the default factory product.
 
-Only inference of the encoder is on the MI355X hot path.  The generator and the
-discriminator are GAN-training components (out of scope): the
-default factories return ``AbsentComponent`` placeholders which satisfy the
-constructor and fail loudly when used; real components can still be injected.
+Only inference of the encoder is on the MI355X hot path.  The discriminator is a
+GAN-training component (out of scope) and the generator is built only
+on request (``cellcomm_amd.generator`` has GPU factories for it): the default
+factories return ``AbsentComponent`` placeholders which satisfy the constructor and
+fail loudly when used; real components can still be injected.
 """
 import numpy as np
 
@@ -119,9 +120,12 @@ class ContinuousCellBiGan(ClassifyCellBiGan):
     """Sigmoid-encoder variant used by the trainer (reference src/bigan_cont.py:44-56,
     src/cell_type_training.py:34)."""
 
-    def __init__(self, encoding_size, gene_size):
+    def __init__(self, encoding_size, gene_size, *, generator_factory=None):
+        # generator_factory (additive to the reference signature): pass
+        # cellcomm_amd.generator.build_cont_generator to make generate_cells run on the GPU; by
+        # default the generator is not built (it holds 0.22·gene_size² weights).
         super().__init__(encoding_size, gene_size,
-                         generator_factory=_absent('cell_generator'),
+                         generator_factory=generator_factory or _absent('cell_generator'),
                          encoder_factory=build_cont_encoder)
 
     def random_encoding_vector(self, batch_size):

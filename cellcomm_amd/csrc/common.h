@@ -62,7 +62,7 @@ int launch_gather(const int64_t *d_indptr, const int32_t *d_indices, const float
 #define CC_GEMM_BK 32
 #endif
 constexpr int GEMM_BM = 128, GEMM_BN = 128, GEMM_BK = CC_GEMM_BK;
-enum Act { ACT_SIGMOID = 0, ACT_LINEAR = 1 };
+enum Act { ACT_SIGMOID = 0, ACT_LINEAR = 1, ACT_RELU = 2 };
 struct PackedWeight {
   float *d_w = nullptr;     // [NT][KT][BK/4][BN][4]
   float *d_bias = nullptr;  // [NT*BN] zero padded

@@ -207,7 +207,7 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
         const int64_t row = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (col_ok && row < M) {
           float z = acc[mt][nt][e] + bcol;
-          C[row * ldc + col] = (act == ACT_SIGMOID) ? sigmoidf_(z) : z;
+          C[row * ldc + col] = (act == ACT_SIGMOID) ? sigmoidf_(z) : (act == ACT_RELU ? fmaxf(z, 0.f) : z);
         }
       }
     }

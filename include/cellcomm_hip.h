@@ -75,6 +75,20 @@ int cc_encoder_set_batch(void *enc, int64_t batch_rows);
  * representable in fp16 and therefore ran on the fp32 kernels instead. */
 int64_t cc_encoder_fp32_fallback_passes(void *enc);
 
+/* ---- generator: replaces keras Model.predict behind BasicBiGan.generate_cells
+ *      (reference src/bigan_basic.py:39-44; graphs src/bigan_cont.py:7-25,
+ *      src/bigan_classify.py:10-25) ---------------------------------------------- */
+
+int cc_generator_create(int arch, int G, int E, void **gen);
+void cc_generator_free(void *gen);
+/* Keras get_weights() order: 20 arrays (cont), 14 (cls); cols == -1 marks a vector. */
+int cc_generator_num_weights(void *gen);
+int cc_generator_weight_shape(void *gen, int idx, int64_t *rows, int64_t *cols);
+int cc_generator_set_weights(void *gen, int idx, const float *host, int64_t rows, int64_t cols);
+/* host_in[n x 2E] = [encoding_in, random_in] per row -> host_out[n x G] (before the rounding
+ * that generate_cells applies). */
+int cc_generate_dense(void *gen, const float *host_in, int64_t n, float *host_out);
+
 /* ---- CSR cell x gene matrix: replaces the dense pivot of
  *      load_matrix (reference src/cell_type_training.py:9-17) ------------- */
 

@@ -164,3 +164,67 @@ def forward_f16(arch, weights, x):
     c = np.concatenate([h, p], axis=-1)
     h = _sigmoid(c @ k3 + b3)
     return _softmax(h @ k4 + b4)
+
+
+# ---- generator (reference src/bigan_cont.py:7-25, src/bigan_classify.py:10-25) -----------------
+
+def generator_weight_shapes(arch, encoding_size, gene_size):
+    """Shapes of the generator's Model.get_weights() in Keras order."""
+    g, i = gene_size, 2 * encoding_size
+    if arch == ARCH_CONT:
+        w0, w1 = int(g * 0.2), int(g * 0.1)
+        return [(i, 50), (50,), (50 + i, 256), (256,), (256, 256), (256,), (256,), (256,), (256,), (256,),
+                (256 + i, w1), (w1,), (w1, w0), (w0,), (w0,), (w0,), (w0,), (w0,), (w0, g), (g,)]
+    return [(i, 50), (50,), (50 + i, 256), (256,), (256,), (256,), (256,), (256,),
+            (256 + i, 256), (256,), (256, 1024), (1024,), (1024, g), (g,)]
+
+
+def generator_weights(arch, encoding_size, gene_size, seed, randomize_bn=True, bias_scale=0.1):
+    rng = np.random.default_rng(seed)
+    shapes = generator_weight_shapes(arch, encoding_size, gene_size)
+    bn_first = (6, 14) if arch == ARCH_CONT else (4,)
+    out = []
+    for idx, shp in enumerate(shapes):
+        if len(shp) == 2:
+            limit = np.sqrt(6.0 / max(shp[0] + shp[1], 1))
+            out.append(rng.uniform(-limit, limit, size=shp).astype(np.float32))
+            continue
+        role = next((idx - f for f in bn_first if 0 <= idx - f < 4), None)
+        n = shp[0]
+        if role is None:
+            out.append((rng.uniform(-1, 1, n) * bias_scale).astype(np.float32))
+        elif randomize_bn:
+            out.append([rng.uniform(0.5, 1.5, n), rng.uniform(-0.5, 0.5, n), rng.uniform(0.2, 0.8, n),
+                        rng.uniform(0.05, 0.5, n)][role].astype(np.float32))
+        else:
+            out.append([np.ones(n), np.zeros(n), np.zeros(n), np.ones(n)][role].astype(np.float32))
+    return out
+
+
+def _bn(h, gamma, beta, mean, var, dtype):
+    return (h - mean) / np.sqrt(var + dtype(BN_EPSILON)) * gamma + beta
+
+
+def generator_forward(arch, weights, encoding_in, random_in, dtype=np.float64):
+    """Generator forward before the rounding of generate_cells (reference src/bigan_basic.py:39-44)."""
+    w = [np.asarray(a, dtype=dtype) for a in weights]
+    all_in = np.concatenate([np.asarray(encoding_in, dtype=np.float32), np.asarray(random_in, dtype=np.float32)],
+                            axis=-1).astype(dtype)
+    relu = lambda z: np.maximum(z, 0)
+    if arch == ARCH_CONT:
+        k1, b1, k2, b2, k3, b3, g1, be1, m1, v1, k4, b4, k5, b5, g2, be2, m2, v2, k6, b6 = w
+        x = _sigmoid(all_in @ k1 + b1)
+        x = _sigmoid(np.concatenate([x, all_in], -1) @ k2 + b2)
+        x = _sigmoid(x @ k3 + b3)
+        x = _bn(x, g1, be1, m1, v1, dtype)
+        x = _sigmoid(np.concatenate([x, all_in], -1) @ k4 + b4)
+        x = relu(x @ k5 + b5)
+        x = _bn(x, g2, be2, m2, v2, dtype)
+        return relu(x @ k6 + b6)
+    k1, b1, k2, b2, g1, be1, m1, v1, k3, b3, k4, b4, k5, b5 = w
+    x = _sigmoid(all_in @ k1 + b1)
+    x = _sigmoid(np.concatenate([x, all_in], -1) @ k2 + b2)
+    x = _bn(x, g1, be1, m1, v1, dtype)
+    x = _sigmoid(np.concatenate([x, all_in], -1) @ k3 + b3)
+    x = relu(x @ k4 + b4)
+    return relu(x @ k5 + b5)

@@ -9,6 +9,7 @@ import pytest
 from conftest import GOLDEN
 from cellcomm_amd import bigan, matrix, pipeline, schema, synth
 from cellcomm_amd.encoder import _layer_plan, hidden_widths
+from oracle import encoder_oracle as eo_mod
 from oracle import loader_oracle as lo
 from oracle import schema_oracle as so
 
@@ -277,3 +278,16 @@ def test_native_parser_random_files_equal_pivot(tmp_path):
         assert got.shape == want.shape, case
         assert np.array_equal(got.index, want.index.to_numpy()) and np.array_equal(got.columns, want.columns.to_numpy())
         assert np.array_equal(got.to_dense(np.float64), want.to_numpy().astype(np.float32).astype(np.float64)), case
+
+
+def test_generator_plan_and_oracle_shapes():
+    from cellcomm_amd import generator
+    for arch, count in (('cont', 20), ('cls', 14)):
+        plan = generator._layer_plan(arch, 13, 100)
+        assert sorted(s for l in plan for s in l[3]) == list(range(count))
+        assert plan[-1][2] == 'relu' and plan[-1][4] == 100                 # reference test/bigans_cc_test.py:24-25,98-99
+        assert [l[0] for l in plan[:2]] == ['gen_encoding_in', 'gen_random_in']   # :19-23
+        ws = eo_mod.generator_weights(arch, 13, 100, seed=1)
+        assert [w.shape for w in ws] == [tuple(s) for s in eo_mod.generator_weight_shapes(arch, 13, 100)]
+        out = eo_mod.generator_forward(arch, ws, np.zeros((3, 13)), np.ones((3, 13)))
+        assert out.shape == (3, 100) and np.all(out >= 0)
