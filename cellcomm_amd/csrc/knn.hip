@@ -815,12 +815,29 @@ __global__ __launch_bounds__(256, 2) void knn_collect16_kernel(
   wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
 }
 
-// sample threshold: T[q] = approximate distance of the m-th best sampled candidate (+inf if fewer)
+// sample threshold: T[q] = approximate distance of the m-th best sampled candidate (+inf if fewer);
+// the sample pass may itself be split over S candidate ranges (S sorted lists per query: m-step merge)
 __global__ void knn_threshold_kernel(const u64 *__restrict__ skeys, const int *__restrict__ scnt, int64_t n_q,
-                                     int KPS, int m, float *__restrict__ T) {
+                                     int S, int KPS, int m, float *__restrict__ T) {
   const int64_t ql = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (ql >= n_q) return;
-  T[ql] = scnt[ql] >= m ? ordered_to_f32((unsigned)(skeys[ql * KPS + m - 1] >> 32)) : INFINITY;
+  int head[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  u64 last = 0;
+  int taken = 0;
+  for (; taken < m; ++taken) {
+    int best = -1;
+    u64 bk = ~0ull;
+    for (int sp = 0; sp < S; ++sp) {
+      if (head[sp] < scnt[ql * S + sp]) {
+        const u64 kx = skeys[(ql * S + sp) * KPS + head[sp]];
+        if (best < 0 || kx < bk) { bk = kx; best = sp; }
+      }
+    }
+    if (best < 0) break;
+    head[best] += 1;
+    last = bk;
+  }
+  T[ql] = taken == m ? ordered_to_f32((unsigned)(last >> 32)) : INFINITY;
 }
 
 // ---- merge: the K' smallest keys of a query's candidate lists -------------------------------------
@@ -1210,12 +1227,28 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
 #define CC_KNN_SAMPLE_SPARE 48
 #endif
       const int KPS = (int)round_up(m, 16), CAPS = KPS + CC_KNN_SAMPLE_SPARE;
-      if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS)))) return rc;
-      if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q))) return rc;
+      // the sample pass is split over candidate ranges too, so that its (long-lived, list-carrying)
+      // waves fill the chip in several short rounds instead of one round plus a nearly empty one
+#ifndef CC_KNN_SAMPLE_ROUNDS
+#define CC_KNN_SAMPLE_ROUNDS 1
+#endif
+      int SS = 1;
+      int64_t NBss = NB;
+      {
+        const size_t sl = sizeof(u64) * 32 * (size_t)(CAPS + 1) + 32 * 8;
+        int64_t wpc = (int64_t)(160 * 1024 / sl);
+        if (wpc > 12) wpc = 12;
+        const int want = (int)ceil_div(CC_KNN_SAMPLE_ROUNDS * 256 * wpc, tiles);
+        make_splits(NB, want > 8 ? 8 : want, &SS, &NBss);
+        while (SS > 1 && NBss / SAMPLE < 4 * m) { --SS; NBss = ceil_div(NB, SS); }   // keep >= 4m sampled blocks per range
+        if (SS == 1) NBss = NB;
+      }
+      if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS) * (size_t)SS))) return rc;
+      if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q * (size_t)SS))) return rc;
       if ((rc = Tq.alloc(sizeof(float) * (size_t)n_q))) return rc;
-      if ((rc = run_select(NG, sa, KPS, CAPS, 1, NB, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) return rc;
+      if ((rc = run_select(NG, sa, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) return rc;
       hipLaunchKernelGGL(knn_threshold_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(),
-                         skeys.as<u64>(), scnts.as<int>(), n_q, KPS, m, Tq.as<float>());
+                         skeys.as<u64>(), scnts.as<int>(), n_q, SS, KPS, m, Tq.as<float>());
       // 1b-ii: collect over all candidates, 8 splits (one per XCD) or fewer for short scans
       make_splits(NB, 8, &S, &NBs);
       if ((rc = cbuf.alloc(sizeof(u64) * (size_t)n_q * (size_t)col_cap))) return rc;
