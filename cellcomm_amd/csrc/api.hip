@@ -100,6 +100,10 @@ struct Encoder {
   _Float16 *xh = nullptr, *h1h = nullptr, *h1l = nullptr;
   int64_t ldxh = 0, ld1h = 0;
   int *d_flag = nullptr;           // gather raises it when a value is not an fp16 number
+  // cont arch, calls longer than one pass: layer-2 outputs of ALL rows, so the three small tail
+  // layers run once over n rows instead of once per pass (39 -> 3 launches at 100k cells)
+  int64_t tail_rows = 0;
+  float *h2_all = nullptr, *h3_all = nullptr, *h4_all = nullptr;
   int64_t fallback_passes = 0;
   int64_t w0 = 0, w1 = 0;  // hidden widths of the first two layers
   int64_t batch = 8192;
@@ -194,6 +198,12 @@ static void encoder_free_ws(Encoder *e) {
   }
   if (e->d_flag) (void)hipFree(e->d_flag);
   e->d_flag = nullptr;
+  float **tb[] = {&e->h2_all, &e->h3_all, &e->h4_all};
+  for (auto b : tb) {
+    if (*b) (void)hipFree(*b);
+    *b = nullptr;
+  }
+  e->tail_rows = 0;
   float **bufs[] = {&e->x, &e->h1, &e->h2, &e->h3, &e->h4};
   for (auto b : bufs) {
     if (*b) (void)hipFree(*b);
@@ -242,7 +252,8 @@ static int encoder_ensure_ws(Encoder *e, int64_t rows) {
 }
 
 // Layers 1-2 on the fp16 matrix cores from M rows already in e->xh (fp16); tail as fp32.
-static int encoder_forward16(Encoder *e, int64_t M, float *out) {
+static int encoder_forward16(Encoder *e, int64_t M, float *out, float *h2_dst = nullptr) {
+  float *h2 = h2_dst ? h2_dst : e->h2;   // h2_dst given: stop after layer 2 (the caller runs the tail)
   int rc;
   const bool split = e->dtype == CC_DTYPE_F16X2;
   const int nt = split ? 2 : 1;
@@ -254,8 +265,9 @@ static int encoder_forward16(Encoder *e, int64_t M, float *out) {
     s1[n1++] = {e->h1h, e->ld1h, 0, nt};
     if (split) s1[n1++] = {e->h1l, e->ld1h, 0, 1};   // third product term A_lo·W_hi of the sigmoid outputs
     s1[n1++] = {e->xh, e->ldxh, 1, nt};
-    if ((rc = launch_gemm16(s1, n1, M, e->L16[1], e->h2, nullptr, e->ld2, 0, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
-    if ((rc = launch_gemm(e->h2, e->ld2, nullptr, 0, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm16(s1, n1, M, e->L16[1], h2, nullptr, e->ld2, 0, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if (h2_dst) return CC_OK;
+    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], e->h4, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h4, e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   } else {
@@ -270,13 +282,15 @@ static int encoder_forward16(Encoder *e, int64_t M, float *out) {
 }
 
 // Layer stack on M dense rows already in e->x; writes out[M x E] (device).
-static int encoder_forward(Encoder *e, int64_t M, float *out) {
+static int encoder_forward(Encoder *e, int64_t M, float *out, float *h2_dst = nullptr) {
   int rc;
+  float *h2 = h2_dst ? h2_dst : e->h2;   // h2_dst given (cont arch only): stop after layer 2
   if (e->arch == CC_ARCH_CONT) {
     // reference src/bigan_cont.py:32-41 (Dropout = identity at inference)
     if ((rc = launch_gemm(e->x, e->ldx, nullptr, 0, M, e->L[0], e->h1, e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
-    if ((rc = launch_gemm(e->h1, e->ld1, e->x, e->ldx, M, e->L[1], e->h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
-    if ((rc = launch_gemm(e->h2, e->ld2, nullptr, 0, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h1, e->ld1, e->x, e->ldx, M, e->L[1], h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if (h2_dst) return CC_OK;
+    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], e->h4, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h4, e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   } else {
@@ -315,6 +329,18 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   const int64_t B = n < e->batch ? n : e->batch;
   if ((rc = encoder_ensure_ws(e, B))) return rc;
   const double nnz_per_row = c->n_rows ? (double)c->nnz / (double)c->n_rows : 0.0;
+  const bool tail_once = e->arch == CC_ARCH_CONT && n > B;
+  if (tail_once && n > e->tail_rows) {
+    float **tb[] = {&e->h2_all, &e->h3_all, &e->h4_all};
+    for (auto b : tb) {
+      if (*b) (void)hipFree(*b);
+      *b = nullptr;
+    }
+    if ((rc = alloc_zero(&e->h2_all, n, e->ld2))) return rc;
+    if ((rc = alloc_zero(&e->h3_all, n, e->ld3))) return rc;
+    if ((rc = alloc_zero(&e->h4_all, n, e->ld3))) return rc;
+    e->tail_rows = n;
+  }
   for (int64_t off = 0; off < n; off += B) {
     const int64_t m = (n - off < B) ? n - off : B;
     const int64_t *d_ids = nullptr;
@@ -334,14 +360,20 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
         CC_HIP(hipStreamSynchronize(stream()));
         if (flag) { fp32_pass = true; e->fallback_passes += 1; }
       }
-      if (!fp32_pass && (rc = encoder_forward16(e, m, dev_out + off * e->E))) return rc;
+      if (!fp32_pass && (rc = encoder_forward16(e, m, dev_out + off * e->E, tail_once ? e->h2_all + off * e->ld2 : nullptr)))
+        return rc;
     }
     if (fp32_pass) {
       if ((rc = launch_gather(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start + off, m, e->G, e->ldx,
                               e->x, nnz_per_row * (double)m)))
         return rc;
-      if ((rc = encoder_forward(e, m, dev_out + off * e->E))) return rc;
+      if ((rc = encoder_forward(e, m, dev_out + off * e->E, tail_once ? e->h2_all + off * e->ld2 : nullptr))) return rc;
     }
+  }
+  if (tail_once) {
+    if ((rc = launch_gemm(e->h2_all, e->ld2, nullptr, 0, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], e->h4_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h4_all, e->ld3, nullptr, 0, n, e->L[4], dev_out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   }
   CC_HIP(hipStreamSynchronize(stream()));
   return CC_OK;
