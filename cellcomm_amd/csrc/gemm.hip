@@ -46,6 +46,10 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #ifndef CC_GEMM_SETPRIO
 #define CC_GEMM_SETPRIO 1
 #endif
+// CC_GEMM_DBUF=1: two LDS stages and ONE barrier per K-step (experiment, see tools/gemm_sweep.sh)
+#ifndef CC_GEMM_DBUF
+#define CC_GEMM_DBUF 0
+#endif
 
 constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
 constexpr int LDS_A_STRIDE = BK + 4;            // floats; (BK+4)·r mod 64 distinct for r mod 16
@@ -75,7 +79,8 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
                           int64_t lda2, int64_t M, const f32x4 *__restrict__ Wp,
                           const float *__restrict__ bias, int KT1, int KT, int N, int MT, int NT,
                           float *__restrict__ C, int64_t ldc, int act) {
-  __shared__ __attribute__((aligned(16))) float lds[BM * LDS_A_STRIDE + TILE_W_FLOAT4 * 4];
+  constexpr int STAGE_FLOATS = BM * LDS_A_STRIDE + TILE_W_FLOAT4 * 4;
+  __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS * (CC_GEMM_DBUF ? 2 : 1)];
   float *As = lds;
   f32x4 *Bs4 = reinterpret_cast<f32x4 *>(lds + BM * LDS_A_STRIDE);
 
@@ -146,6 +151,7 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   const float *a_lds = As + (wm * 64 + r) * LDS_A_STRIDE + 4 * h;
   const f32x4 *b_lds = Bs4 + h * BN + wn * 64 + r;
 
+#if !CC_GEMM_DBUF
   for (int kt = 0; kt < KT; ++kt) {
     const bool more = kt + 1 < KT;  // wave-uniform
     if (more) {
@@ -194,6 +200,64 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
     __syncthreads();
   }
 
+#else
+  int cur = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + 1 < KT;  // wave-uniform
+    if (more) {
+      if (kt + 1 == KT1) {
+        const float *base = A2 + m0 * lda2;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * (int)lda2 + 4 * a_k4;
+      }
+#pragma unroll
+      for (int p = 0; p < NA; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
+#pragma unroll
+      for (int p = 0; p < NB; ++p) rb[p] = wt[p * GEMM_THREADS];
+      wt += TILE_W_FLOAT4;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float *a_cur = a_lds + cur * STAGE_FLOATS;
+    const f32x4 *b_cur = b_lds + cur * (STAGE_FLOATS / 4);
+#if CC_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+#pragma unroll
+    for (int t = 0; t < BK / 8; ++t) {
+      if (t == BK / 8 - 1) {
+        // the next tile goes into the other stage (last read one K-step ago, every wave is past that
+        // barrier) while the last quarter of this K-step's MFMAs is still to be issued
+#if CC_GEMM_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
+        if (more) {
+          float *aw = As + (cur ^ 1) * STAGE_FLOATS + a_row * LDS_A_STRIDE + 4 * a_k4;
+          f32x4 *bw = Bs4 + (cur ^ 1) * (STAGE_FLOATS / 4);
+#pragma unroll
+          for (int p = 0; p < NA; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
+#pragma unroll
+          for (int p = 0; p < NB; ++p) bw[tid + p * GEMM_THREADS] = rb[p];
+        }
+      }
+      f32x4 a[2], b[2];
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+        a[mt] = *reinterpret_cast<const f32x4 *>(a_cur + mt * 32 * LDS_A_STRIDE + 8 * t);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) b[nt] = b_cur[2 * t * BN + nt * 32];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][u], b[nt][u], acc[mt][nt], 0, 0, 0);
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+
+#endif
   // ---- epilogue: bias + activation, 128-byte row segments per half-wave ------
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
