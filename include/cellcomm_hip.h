@@ -139,7 +139,9 @@ void cc_mtx_free(void *mtx);
  * (float32).  Order: (distance asc, index asc); distance is the float64
  * sequential sum of squared float64 differences, returned rounded to float32.
  * include_self = 0 drops candidate j == query index.  idx holds GLOBAL row
- * indices (int32).  Requires k <= n_total - (include_self ? 0 : 1). */
+ * indices (int32).  Requires k <= n_total - (include_self ? 0 : 1); supported 1 <= k <= 128,
+ * 1 <= d <= 132, n_total < 2^31.  Scratch buffers are kept per process on the device chosen by
+ * cc_init (one process per GPU). */
 int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_self,
               int32_t *host_idx, float *host_dist);
 int cc_knn_l2_dev(const float *dev_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q,
