@@ -101,10 +101,24 @@ def write_enc_file(path, encodings):
         pickle.dump(np.asarray(encodings), f)
 
 
+class _ArrayOnlyUnpickler(pickle.Unpickler):
+    """`.enc` files are pickles (the format reference import_encodings.py:24-27 reads).  Loading one
+    must not execute anything: only the globals needed to rebuild a plain ndarray / nested lists of
+    numbers are resolvable, everything else is refused."""
+    _ALLOWED = {('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'),
+                ('numpy', 'ndarray'), ('numpy', 'dtype'), ('numpy.core.multiarray', 'scalar'),
+                ('numpy._core.multiarray', 'scalar')}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f'.enc file references {module}.{name}: only plain arrays are accepted')
+
+
 def read_enc_file(path):
-    """Reads a file written by write_enc_file (never a reference-shipped pickle)."""
+    """Encodings array of an `.enc` file (array-only unpickling, see _ArrayOnlyUnpickler)."""
     with open(path, 'rb') as f:
-        return np.asarray(pickle.load(f))
+        return np.asarray(_ArrayOnlyUnpickler(f).load())
 
 
 def load_barcodes(barcode_file):

@@ -96,7 +96,8 @@ int cc_generate_dense(void *gen, const float *host_in, int64_t n, float *host_ou
  * < G), vals[nnz] float32.  Copies to the device. */
 int cc_csr_upload(const int64_t *indptr, const int32_t *indices, const float *vals,
                   int64_t n_rows, int64_t nnz, int G, void **csr);
-/* Adopt device-resident CSR arrays (not copied, not freed by cc_csr_free). */
+/* Adopt device-resident CSR arrays (not copied, not freed by cc_csr_free).  The caller guarantees
+ * the same canonical form cc_csr_upload checks (columns strictly increasing per row, < G). */
 int cc_csr_wrap_device(const int64_t *dev_indptr, const int32_t *dev_indices, const float *dev_vals,
                        int64_t n_rows, int64_t nnz, int G, void **csr);
 void cc_csr_free(void *csr);

@@ -166,6 +166,13 @@ def test_enc_file_roundtrip_and_knn_fields(tmp_path):
     path = tmp_path / '5009.enc'
     schema.write_enc_file(path, enc)
     assert np.array_equal(schema.read_enc_file(path), enc)
+    schema.write_enc_file(path, enc.tolist())                     # nested lists are legal .enc content too
+    assert np.allclose(schema.read_enc_file(path), enc)
+    import pickle
+    with open(path, 'wb') as f:                                     # a pickle that would run code is refused
+        pickle.dump(print, f)
+    with pytest.raises(pickle.UnpicklingError):
+        schema.read_enc_file(path)
     idx = np.arange(18, dtype=np.int32).reshape(9, 2) % 9
     doc = schema.encits_document('e', 1, enc, list('abcdefghi'), knn=(idx, idx.astype(np.float32)))
     assert doc['nn'][0] == [1, 2] and len(doc['nd']) == 9
