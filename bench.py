@@ -76,8 +76,16 @@ def cpu_baseline(args, enc, local, enc_host):
     per_pair = t_knn / (nk * nk)
     per_cell = t_enc / ns + per_pair * args.cells
     rel = float(np.max(np.abs(out - enc_host[:ns]) / np.abs(out))) if local.row_ids() is None else None
+    blas_threads = None
+    try:
+        from threadpoolctl import threadpool_info
+        blas_threads = max((p.get('num_threads', 0) for p in threadpool_info() if p.get('user_api') == 'blas'), default=None)
+    except Exception:
+        pass
+    omp_threads = int(os.environ.get('OMP_NUM_THREADS', 0)) or os.cpu_count()
     return {
-        'value': 1.0 / per_cell, 'unit': 'cells/s', 'cores': os.cpu_count(), 'kind': 'port',
+        'value': 1.0 / per_cell, 'unit': 'cells/s', 'cores': max(blas_threads or 0, omp_threads), 'kind': 'port',
+        'blas_threads': blas_threads, 'openmp_threads': omp_threads, 'host_cpus': os.cpu_count(),
         'sample': f'oracle fp32 NumPy/BLAS forward on {ns} cells x {args.genes} genes in one batch '
                   f'({t_enc:.2f} s) + oracle/knn_oracle.c (OpenMP) on {nk} x {nk} encodings ({t_knn:.2f} s), '
                   f'kNN cost scaled per candidate pair to {args.cells} candidates',
