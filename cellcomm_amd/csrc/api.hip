@@ -8,7 +8,9 @@
 namespace cc {
 
 static thread_local std::string g_err;
-static hipStream_t g_stream = nullptr;
+static hipStream_t g_stream = nullptr;    // the library stream
+static hipStream_t g_stream2 = nullptr;   // second stream: alternate passes of a short encode call run on it
+static hipStream_t g_cur = nullptr;       // stream the launchers currently issue on (g_stream unless overridden)
 static int g_device = -1;
 
 void set_error(const char *fmt, ...) {
@@ -19,7 +21,7 @@ void set_error(const char *fmt, ...) {
   va_end(ap);
   g_err = buf;
 }
-hipStream_t stream() { return g_stream; }
+hipStream_t stream() { return g_cur ? g_cur : g_stream; }
 bool initialised() { return g_stream != nullptr; }
 
 // ---- profiling ---------------------------------------------------------------
@@ -47,16 +49,17 @@ ProfScope::ProfScope(int klass_, double work_) : klass(klass_), work(work_) {
   e0 = event_get();
   e1 = event_get();
   if (!e0 || !e1) { e0 = e1 = nullptr; return; }
-  (void)hipEventRecord(e0, g_stream);
+  (void)hipEventRecord(e0, stream());
 }
 ProfScope::~ProfScope() {
   if (!e0 || !e1) return;
-  (void)hipEventRecord(e1, g_stream);
+  (void)hipEventRecord(e1, stream());
   g_pending.push_back({klass, work, e0, e1});
 }
 static void prof_drain() {
   if (g_pending.empty()) return;
   (void)hipStreamSynchronize(g_stream);
+  if (g_stream2) (void)hipStreamSynchronize(g_stream2);
   for (auto &r : g_pending) {
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, r.e0, r.e1) == hipSuccess) {
@@ -97,9 +100,9 @@ struct Encoder {
   int arch = 0, G = 0, E = 0;
   int dtype = CC_DTYPE_F32;
   PackedWeight16 L16[2];           // layers 1-2 for the fp16-MFMA modes
-  _Float16 *xh = nullptr, *h1h = nullptr, *h1l = nullptr;
+  _Float16 *xh[2] = {nullptr, nullptr}, *h1h[2] = {nullptr, nullptr}, *h1l[2] = {nullptr, nullptr};
   int64_t ldxh = 0, ld1h = 0;
-  int *d_flag = nullptr;           // gather raises it when a value is not an fp16 number
+  int *d_flag[2] = {nullptr, nullptr};  // gather raises it when a value is not an fp16 number
   // cont arch, calls longer than one pass: layer-2 outputs of ALL rows, so the three small tail
   // layers run once over n rows instead of once per pass (39 -> 3 launches at 100k cells)
   int64_t tail_rows = 0;
@@ -116,8 +119,11 @@ struct Encoder {
   // workspace
   int64_t ws_rows = 0;
   int64_t ldx = 0, ld1 = 0, ld2 = 0, ld3 = 0;
-  float *x = nullptr, *h1 = nullptr, *h2 = nullptr, *h3 = nullptr, *h4 = nullptr;
-  int64_t *d_row_ids = nullptr;
+  // two workspace slots: alternate passes of a short call run on two streams (see encode_csr_dev)
+  float *x[2] = {nullptr, nullptr}, *h1[2] = {nullptr, nullptr}, *h2[2] = {nullptr, nullptr};
+  float *h3[2] = {nullptr, nullptr}, *h4[2] = {nullptr, nullptr};
+  int64_t *d_row_ids[2] = {nullptr, nullptr};
+  int ws_slots = 0;
 };
 
 static int64_t pad32(int64_t v) { return v == 0 ? GEMM_BK : round_up(v, GEMM_BK); }  // pad to the GEMM K-step
@@ -191,26 +197,29 @@ static int encoder_pack(Encoder *e) {
 }
 
 static void encoder_free_ws(Encoder *e) {
-  _Float16 **hb[] = {&e->xh, &e->h1h, &e->h1l};
-  for (auto b : hb) {
-    if (*b) (void)hipFree(*b);
-    *b = nullptr;
+  for (int sl = 0; sl < 2; ++sl) {
+    _Float16 **hb[] = {&e->xh[sl], &e->h1h[sl], &e->h1l[sl]};
+    for (auto b : hb) {
+      if (*b) (void)hipFree(*b);
+      *b = nullptr;
+    }
+    if (e->d_flag[sl]) (void)hipFree(e->d_flag[sl]);
+    e->d_flag[sl] = nullptr;
+    float **bufs[] = {&e->x[sl], &e->h1[sl], &e->h2[sl], &e->h3[sl], &e->h4[sl]};
+    for (auto b : bufs) {
+      if (*b) (void)hipFree(*b);
+      *b = nullptr;
+    }
+    if (e->d_row_ids[sl]) (void)hipFree(e->d_row_ids[sl]);
+    e->d_row_ids[sl] = nullptr;
   }
-  if (e->d_flag) (void)hipFree(e->d_flag);
-  e->d_flag = nullptr;
+  e->ws_slots = 0;
   float **tb[] = {&e->h2_all, &e->h3_all, &e->h4_all};
   for (auto b : tb) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
   }
   e->tail_rows = 0;
-  float **bufs[] = {&e->x, &e->h1, &e->h2, &e->h3, &e->h4};
-  for (auto b : bufs) {
-    if (*b) (void)hipFree(*b);
-    *b = nullptr;
-  }
-  if (e->d_row_ids) (void)hipFree(e->d_row_ids);
-  e->d_row_ids = nullptr;
   e->ws_rows = 0;
 }
 
@@ -221,84 +230,88 @@ static int alloc_zero(float **p, int64_t rows, int64_t ld) {
   return CC_OK;
 }
 
-static int encoder_ensure_ws(Encoder *e, int64_t rows) {
-  if (rows <= e->ws_rows) return CC_OK;
+static int encoder_ensure_ws(Encoder *e, int64_t rows, int slots) {
+  if (rows <= e->ws_rows && slots <= e->ws_slots) return CC_OK;
+  if (rows < e->ws_rows) rows = e->ws_rows;
   encoder_free_ws(e);
   e->ldx = pad32(e->G);
   e->ld1 = pad32(e->w0);
   e->ld2 = pad32(e->w1);
   e->ld3 = pad32(150);
   int rc;
-  if ((rc = alloc_zero(&e->x, rows, e->ldx))) return rc;
-  if ((rc = alloc_zero(&e->h1, rows, e->ld1))) return rc;
-  if ((rc = alloc_zero(&e->h2, rows, e->ld2))) return rc;
-  if ((rc = alloc_zero(&e->h3, rows, e->ld3))) return rc;
-  if ((rc = alloc_zero(&e->h4, rows, e->ld3))) return rc;
-  CC_HIP(hipMalloc(&e->d_row_ids, sizeof(int64_t) * (size_t)rows));
-  if (e->dtype != CC_DTYPE_F32) {
-    e->ldxh = round_up(e->G, 64);
-    e->ld1h = e->w0 == 0 ? 64 : round_up(e->w0, 64);
-    const size_t bx = sizeof(_Float16) * (size_t)(rows * e->ldxh), b1 = sizeof(_Float16) * (size_t)(rows * e->ld1h);
-    CC_HIP(hipMalloc(&e->xh, bx));
-    CC_HIP(hipMalloc(&e->h1h, b1));
-    CC_HIP(hipMalloc(&e->h1l, b1));
-    CC_HIP(hipMemsetAsync(e->xh, 0, bx, stream()));
-    CC_HIP(hipMemsetAsync(e->h1h, 0, b1, stream()));
-    CC_HIP(hipMemsetAsync(e->h1l, 0, b1, stream()));
-    CC_HIP(hipMalloc(&e->d_flag, sizeof(int)));
+  for (int sl = 0; sl < slots; ++sl) {
+    if ((rc = alloc_zero(&e->x[sl], rows, e->ldx))) return rc;
+    if ((rc = alloc_zero(&e->h1[sl], rows, e->ld1))) return rc;
+    if ((rc = alloc_zero(&e->h2[sl], rows, e->ld2))) return rc;
+    if ((rc = alloc_zero(&e->h3[sl], rows, e->ld3))) return rc;
+    if ((rc = alloc_zero(&e->h4[sl], rows, e->ld3))) return rc;
+    CC_HIP(hipMalloc(&e->d_row_ids[sl], sizeof(int64_t) * (size_t)rows));
+    if (e->dtype != CC_DTYPE_F32) {
+      e->ldxh = round_up(e->G, 64);
+      e->ld1h = e->w0 == 0 ? 64 : round_up(e->w0, 64);
+      const size_t bx = sizeof(_Float16) * (size_t)(rows * e->ldxh), b1 = sizeof(_Float16) * (size_t)(rows * e->ld1h);
+      CC_HIP(hipMalloc(&e->xh[sl], bx));
+      CC_HIP(hipMalloc(&e->h1h[sl], b1));
+      CC_HIP(hipMalloc(&e->h1l[sl], b1));
+      CC_HIP(hipMemsetAsync(e->xh[sl], 0, bx, stream()));
+      CC_HIP(hipMemsetAsync(e->h1h[sl], 0, b1, stream()));
+      CC_HIP(hipMemsetAsync(e->h1l[sl], 0, b1, stream()));
+      CC_HIP(hipMalloc(&e->d_flag[sl], sizeof(int)));
+    }
   }
+  e->ws_slots = slots;
   e->ws_rows = rows;
   return CC_OK;
 }
 
-// Layers 1-2 on the fp16 matrix cores from M rows already in e->xh (fp16); tail as fp32.
-static int encoder_forward16(Encoder *e, int64_t M, float *out, float *h2_dst = nullptr) {
-  float *h2 = h2_dst ? h2_dst : e->h2;   // h2_dst given: stop after layer 2 (the caller runs the tail)
+// Layers 1-2 on the fp16 matrix cores from M rows already in e->xh[sl] (fp16); tail as fp32.
+static int encoder_forward16(Encoder *e, int sl, int64_t M, float *out, float *h2_dst = nullptr) {
+  float *h2 = h2_dst ? h2_dst : e->h2[sl];   // h2_dst given: stop after layer 2 (the caller runs the tail)
   int rc;
   const bool split = e->dtype == CC_DTYPE_F16X2;
   const int nt = split ? 2 : 1;
   if (e->arch == CC_ARCH_CONT) {
-    const GemmSeg16 s0[1] = {{e->xh, e->ldxh, 0, nt}};
-    if ((rc = launch_gemm16(s0, 1, M, e->L16[0], e->h1h, split ? e->h1l : nullptr, e->ld1h, 1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
+    const GemmSeg16 s0[1] = {{e->xh[sl], e->ldxh, 0, nt}};
+    if ((rc = launch_gemm16(s0, 1, M, e->L16[0], e->h1h[sl], split ? e->h1l[sl] : nullptr, e->ld1h, 1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
     GemmSeg16 s1[3];
     int n1 = 0;
-    s1[n1++] = {e->h1h, e->ld1h, 0, nt};
-    if (split) s1[n1++] = {e->h1l, e->ld1h, 0, 1};   // third product term A_lo·W_hi of the sigmoid outputs
-    s1[n1++] = {e->xh, e->ldxh, 1, nt};
+    s1[n1++] = {e->h1h[sl], e->ld1h, 0, nt};
+    if (split) s1[n1++] = {e->h1l[sl], e->ld1h, 0, 1};   // third product term A_lo·W_hi of the sigmoid outputs
+    s1[n1++] = {e->xh[sl], e->ldxh, 1, nt};
     if ((rc = launch_gemm16(s1, n1, M, e->L16[1], h2, nullptr, e->ld2, 0, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
     if (h2_dst) return CC_OK;
-    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], e->h4, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h4, e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], e->h4[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h4[sl], e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   } else {
-    const GemmSeg16 s0[1] = {{e->xh, e->ldxh, 0, nt}};
-    if ((rc = launch_gemm16(s0, 1, M, e->L16[0], e->h1, nullptr, e->ld1, 0, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
-    if ((rc = launch_gemm(e->h1, e->ld1, nullptr, 0, M, e->L[1], e->h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
-    if ((rc = launch_gemm(e->h2, e->ld2, e->h1, e->ld1, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
+    const GemmSeg16 s0[1] = {{e->xh[sl], e->ldxh, 0, nt}};
+    if ((rc = launch_gemm16(s0, 1, M, e->L16[0], e->h1[sl], nullptr, e->ld1, 0, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
+    if ((rc = launch_gemm(e->h1[sl], e->ld1, nullptr, 0, M, e->L[1], e->h2[sl], e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->h2[sl], e->ld2, e->h1[sl], e->ld1, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_row_softmax(out, M, e->E, e->E))) return rc;
   }
   return CC_OK;
 }
 
-// Layer stack on M dense rows already in e->x; writes out[M x E] (device).
-static int encoder_forward(Encoder *e, int64_t M, float *out, float *h2_dst = nullptr) {
+// Layer stack on M dense rows already in e->x[sl]; writes out[M x E] (device).
+static int encoder_forward(Encoder *e, int sl, int64_t M, float *out, float *h2_dst = nullptr) {
   int rc;
-  float *h2 = h2_dst ? h2_dst : e->h2;   // h2_dst given (cont arch only): stop after layer 2
+  float *h2 = h2_dst ? h2_dst : e->h2[sl];   // h2_dst given (cont arch only): stop after layer 2
   if (e->arch == CC_ARCH_CONT) {
     // reference src/bigan_cont.py:32-41 (Dropout = identity at inference)
-    if ((rc = launch_gemm(e->x, e->ldx, nullptr, 0, M, e->L[0], e->h1, e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
-    if ((rc = launch_gemm(e->h1, e->ld1, e->x, e->ldx, M, e->L[1], h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
+    if ((rc = launch_gemm(e->h1[sl], e->ld1, e->x[sl], e->ldx, M, e->L[1], h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
     if (h2_dst) return CC_OK;
-    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], e->h4, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h4, e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], e->h4[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h4[sl], e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   } else {
     // reference src/bigan_classify.py:31-39: p → h → concat[h, p] → 150 → softmax(E)
-    if ((rc = launch_gemm(e->x, e->ldx, nullptr, 0, M, e->L[0], e->h1, e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
-    if ((rc = launch_gemm(e->h1, e->ld1, nullptr, 0, M, e->L[1], e->h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
-    if ((rc = launch_gemm(e->h2, e->ld2, e->h1, e->ld1, M, e->L[2], e->h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h3, e->ld3, nullptr, 0, M, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
+    if ((rc = launch_gemm(e->h1[sl], e->ld1, nullptr, 0, M, e->L[1], e->h2[sl], e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->h2[sl], e->ld2, e->h1[sl], e->ld1, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_row_softmax(out, M, e->E, e->E))) return rc;
   }
   return CC_OK;
@@ -326,8 +339,16 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   if (e->dirty && (rc = encoder_pack(e))) return rc;
   e->fallback_passes = 0;
   if (n == 0) return CC_OK;
-  const int64_t B = n < e->batch ? n : e->batch;
-  if ((rc = encoder_ensure_ws(e, B))) return rc;
+  int64_t B = n < e->batch ? n : e->batch;
+  const int64_t npass = ceil_div(n, B);
+  // GEMM time is quantised in rounds of 768 resident tiles, so the short last pass of a call (and
+  // both passes of a 12 500-row shard) leave most CUs idle in their final round.  For short calls
+  // alternate passes therefore run on two streams with their own workspaces: the idle CUs of one
+  // pass's last round take tiles of the other pass.  Long calls (the 100k single-GPU case: 12 passes
+  // of exactly 2 + 1 rounds) stay on one stream, where per-kernel timings also stay meaningful.
+  const bool dual = npass >= 2 && npass <= 4;
+  if (dual) B = round_up(ceil_div(n, npass), GEMM_BM);   // equal passes pack best when two of them overlap
+  if ((rc = encoder_ensure_ws(e, B, dual ? 2 : 1))) return rc;
   const double nnz_per_row = c->n_rows ? (double)c->nnz / (double)c->n_rows : 0.0;
   const bool tail_once = e->arch == CC_ARCH_CONT && n > B;
   if (tail_once && n > e->tail_rows) {
@@ -341,35 +362,42 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
     if ((rc = alloc_zero(&e->h4_all, n, e->ld3))) return rc;
     e->tail_rows = n;
   }
-  for (int64_t off = 0; off < n; off += B) {
+  if (dual) CC_HIP(hipStreamSynchronize(g_stream));   // workspace / h2_all memsets are on the library stream
+  struct StreamReset { ~StreamReset() { g_cur = nullptr; } } stream_reset;
+  int64_t pass = 0;
+  for (int64_t off = 0; off < n; off += B, ++pass) {
+    const int sl = dual ? (int)(pass & 1) : 0;
+    g_cur = sl ? g_stream2 : g_stream;
     const int64_t m = (n - off < B) ? n - off : B;
     const int64_t *d_ids = nullptr;
     if (row_ids) {
-      CC_HIP(hipMemcpyAsync(e->d_row_ids, row_ids + off, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, stream()));
-      d_ids = e->d_row_ids;
+      CC_HIP(hipMemcpyAsync(e->d_row_ids[sl], row_ids + off, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, stream()));
+      d_ids = e->d_row_ids[sl];
     }
     bool fp32_pass = e->dtype == CC_DTYPE_F32;
     if (!fp32_pass) {
-      CC_HIP(hipMemsetAsync(e->d_flag, 0, sizeof(int), stream()));
+      CC_HIP(hipMemsetAsync(e->d_flag[sl], 0, sizeof(int), stream()));
       if ((rc = launch_gather_f16(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start + off, m, e->G,
-                                  e->ldxh, e->xh, e->d_flag, nnz_per_row * (double)m)))
+                                  e->ldxh, e->xh[sl], e->d_flag[sl], nnz_per_row * (double)m)))
         return rc;
       if (e->dtype == CC_DTYPE_F16X2) {   // the 2-term raw-input product needs fp16-exact values
         int flag = 0;
-        CC_HIP(hipMemcpyAsync(&flag, e->d_flag, sizeof(int), hipMemcpyDeviceToHost, stream()));
+        CC_HIP(hipMemcpyAsync(&flag, e->d_flag[sl], sizeof(int), hipMemcpyDeviceToHost, stream()));
         CC_HIP(hipStreamSynchronize(stream()));
         if (flag) { fp32_pass = true; e->fallback_passes += 1; }
       }
-      if (!fp32_pass && (rc = encoder_forward16(e, m, dev_out + off * e->E, tail_once ? e->h2_all + off * e->ld2 : nullptr)))
+      if (!fp32_pass && (rc = encoder_forward16(e, sl, m, dev_out + off * e->E, tail_once ? e->h2_all + off * e->ld2 : nullptr)))
         return rc;
     }
     if (fp32_pass) {
       if ((rc = launch_gather(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start + off, m, e->G, e->ldx,
-                              e->x, nnz_per_row * (double)m)))
+                              e->x[sl], nnz_per_row * (double)m)))
         return rc;
-      if ((rc = encoder_forward(e, m, dev_out + off * e->E, tail_once ? e->h2_all + off * e->ld2 : nullptr))) return rc;
+      if ((rc = encoder_forward(e, sl, m, dev_out + off * e->E, tail_once ? e->h2_all + off * e->ld2 : nullptr))) return rc;
     }
   }
+  g_cur = nullptr;
+  if (dual) CC_HIP(hipStreamSynchronize(g_stream2));   // join before the tail / before returning
   if (tail_once) {
     if ((rc = launch_gemm(e->h2_all, e->ld2, nullptr, 0, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], e->h4_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
@@ -407,7 +435,10 @@ int cc_init(int device) {
   }
   if (g_stream && g_device == device) return CC_OK;
   if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
+  if (g_stream2) { (void)hipStreamDestroy(g_stream2); g_stream2 = nullptr; }
+  g_cur = nullptr;
   CC_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+  CC_HIP(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
   g_device = device;
   return CC_OK;
 }
@@ -598,12 +629,13 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
   e->fallback_passes = 0;
   if (n == 0) return CC_OK;
   const int64_t B = n < e->batch ? n : e->batch;
-  if ((rc = encoder_ensure_ws(e, B))) return rc;
+  if ((rc = encoder_ensure_ws(e, B, 1))) return rc;
+  const int sl = 0;
   float *d_out = nullptr;
   CC_HIP(hipMalloc(&d_out, sizeof(float) * (size_t)(n * e->E)));
   for (int64_t off = 0; off < n && rc == CC_OK; off += B) {
     const int64_t m = (n - off < B) ? n - off : B;
-    if (hipMemcpy2DAsync(e->x, sizeof(float) * (size_t)e->ldx, host_x + off * e->G, sizeof(float) * (size_t)e->G,
+    if (hipMemcpy2DAsync(e->x[sl], sizeof(float) * (size_t)e->ldx, host_x + off * e->G, sizeof(float) * (size_t)e->G,
                          sizeof(float) * (size_t)e->G, (size_t)m, hipMemcpyHostToDevice, stream()) != hipSuccess) {
       set_error("hipMemcpy2D H2D failed in cc_encode_dense");
       rc = CC_EHIP;
@@ -612,16 +644,16 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
     bool fp32_pass = e->dtype == CC_DTYPE_F32;
     if (!fp32_pass) {
       int flag = 0;
-      if (hipMemsetAsync(e->d_flag, 0, sizeof(int), stream()) != hipSuccess) { set_error("memset failed"); rc = CC_EHIP; break; }
-      rc = launch_convert_f16(e->x, e->ldx, m, e->G, e->xh, e->ldxh, e->d_flag);
+      if (hipMemsetAsync(e->d_flag[sl], 0, sizeof(int), stream()) != hipSuccess) { set_error("memset failed"); rc = CC_EHIP; break; }
+      rc = launch_convert_f16(e->x[sl], e->ldx, m, e->G, e->xh[sl], e->ldxh, e->d_flag[sl]);
       if (rc == CC_OK && e->dtype == CC_DTYPE_F16X2) {
-        if (hipMemcpyAsync(&flag, e->d_flag, sizeof(int), hipMemcpyDeviceToHost, stream()) != hipSuccess ||
+        if (hipMemcpyAsync(&flag, e->d_flag[sl], sizeof(int), hipMemcpyDeviceToHost, stream()) != hipSuccess ||
             hipStreamSynchronize(stream()) != hipSuccess) { set_error("flag read failed"); rc = CC_EHIP; break; }
         if (flag) { fp32_pass = true; e->fallback_passes += 1; }
       }
-      if (rc == CC_OK && !fp32_pass) rc = encoder_forward16(e, m, d_out + off * e->E);
+      if (rc == CC_OK && !fp32_pass) rc = encoder_forward16(e, sl, m, d_out + off * e->E);
     }
-    if (rc == CC_OK && fp32_pass) rc = encoder_forward(e, m, d_out + off * e->E);
+    if (rc == CC_OK && fp32_pass) rc = encoder_forward(e, sl, m, d_out + off * e->E);
     // the staging buffer is reused by the next pass
     if (rc == CC_OK && hipStreamSynchronize(stream()) != hipSuccess) {
       set_error("stream synchronise failed in cc_encode_dense");
