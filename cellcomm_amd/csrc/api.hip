@@ -339,15 +339,33 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   if (e->dirty && (rc = encoder_pack(e))) return rc;
   e->fallback_passes = 0;
   if (n == 0) return CC_OK;
-  int64_t B = n < e->batch ? n : e->batch;
-  const int64_t npass = ceil_div(n, B);
-  // GEMM time is quantised in rounds of 768 resident tiles, so the short last pass of a call (and
-  // both passes of a 12 500-row shard) leave most CUs idle in their final round.  For short calls
-  // alternate passes therefore run on two streams with their own workspaces: the idle CUs of one
-  // pass's last round take tiles of the other pass.  Long calls (the 100k single-GPU case: 12 passes
-  // of exactly 2 + 1 rounds) stay on one stream, where per-kernel timings also stay meaningful.
-  const bool dual = npass >= 2 && npass <= 4;
-  if (dual) B = round_up(ceil_div(n, npass), GEMM_BM);   // equal passes pack best when two of them overlap
+  // Pass plan.  GEMM time is quantised in rounds of 768 resident tiles, so a short pass leaves most
+  // CUs idle in its final round.  Calls of 2-4 passes (the per-rank shards at 4 and 8 GPUs) are cut
+  // into equal passes that alternate between two streams with their own workspaces: the idle CUs of
+  // one pass's last round then take tiles of the other.  Calls of 5-8 passes (2 GPUs) do the same
+  // with their last two passes only.  Longer calls (the 100k single-GPU case: 8192-row passes are
+  // exactly 2 + 1 rounds for layers 1 and 2) stay on one stream, where per-kernel timings also
+  // stay meaningful.
+  struct Pass { int64_t off, m; int slot; };
+  std::vector<Pass> plan;
+  int64_t lead_passes = 0;   // full passes in front of the overlapped pair (stream 2 waits for them)
+  const int64_t full = e->batch;
+  const int64_t npass = ceil_div(n, full);
+  int64_t B = n < full ? n : full;
+  bool dual = false;
+  if (npass >= 2 && npass <= 8) {
+    dual = true;
+    const int64_t lead = npass <= 4 ? 0 : npass - 2;          // full-size passes in front
+    lead_passes = lead;
+    int64_t off = 0;
+    for (int64_t i = 0; i < lead; ++i, off += full) plan.push_back({off, full, 0});
+    const int64_t rest = n - off, parts = npass - lead;
+    const int64_t each = round_up(ceil_div(rest, parts), GEMM_BM);
+    for (int64_t i = 0; off < n; ++i, off += each) plan.push_back({off, (n - off < each) ? n - off : each, (int)(i & 1)});
+    if (each > B) B = each;
+  } else {
+    for (int64_t off = 0; off < n; off += B) plan.push_back({off, (n - off < B) ? n - off : B, 0});
+  }
   if ((rc = encoder_ensure_ws(e, B, dual ? 2 : 1))) return rc;
   const double nnz_per_row = c->n_rows ? (double)c->nnz / (double)c->n_rows : 0.0;
   const bool tail_once = e->arch == CC_ARCH_CONT && n > B;
@@ -364,11 +382,18 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   }
   if (dual) CC_HIP(hipStreamSynchronize(g_stream));   // workspace / h2_all memsets are on the library stream
   struct StreamReset { ~StreamReset() { g_cur = nullptr; } } stream_reset;
-  int64_t pass = 0;
-  for (int64_t off = 0; off < n; off += B, ++pass) {
-    const int sl = dual ? (int)(pass & 1) : 0;
+  static hipEvent_t lead_done = nullptr;
+  if (lead_passes > 0 && !lead_done) CC_HIP(hipEventCreateWithFlags(&lead_done, hipEventDisableTiming));
+  int64_t pass_no = 0;
+  for (const Pass &ps : plan) {
+    const int sl = ps.slot;
+    const int64_t off = ps.off, m = ps.m;
+    if (lead_passes > 0 && pass_no == lead_passes) {   // the overlapped pair starts together, after the full passes
+      CC_HIP(hipEventRecord(lead_done, g_stream));
+      CC_HIP(hipStreamWaitEvent(g_stream2, lead_done, 0));
+    }
+    ++pass_no;
     g_cur = sl ? g_stream2 : g_stream;
-    const int64_t m = (n - off < B) ? n - off : B;
     const int64_t *d_ids = nullptr;
     if (row_ids) {
       CC_HIP(hipMemcpyAsync(e->d_row_ids[sl], row_ids + off, sizeof(int64_t) * (size_t)m, hipMemcpyHostToDevice, stream()));
