@@ -259,8 +259,11 @@ __device__ __forceinline__ void select_step(const float4 (&a)[NG], const float4 
   }
 }
 
+#ifndef CC_KNN_SEL_MINW
+#define CC_KNN_SEL_MINW 3
+#endif
 template <int NG>
-__global__ __launch_bounds__(64, 3) void knn_select_kernel(
+__global__ __launch_bounds__(64, CC_KNN_SEL_MINW) void knn_select_kernel(
     const float4 *__restrict__ P, const float *__restrict__ norms, const float *__restrict__ x,
     const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
     int KP, int CAP, int S, int64_t NBs, int bstride, u64 *__restrict__ out_keys, int *__restrict__ out_cnt) {
