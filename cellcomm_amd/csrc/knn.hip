@@ -818,6 +818,11 @@ __global__ __launch_bounds__(256, 2) void knn_collect16_kernel(
   wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
 }
 
+__global__ void knn_fill_kernel(float *__restrict__ p, int64_t n, float v) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 // sample threshold: T[q] = approximate distance of the m-th best sampled candidate (+inf if fewer);
 // the sample pass may itself be split over S candidate ranges (S sorted lists per query: m-step merge)
 __global__ void knn_threshold_kernel(const u64 *__restrict__ skeys, const int *__restrict__ scnt, int64_t n_q,
@@ -1176,8 +1181,16 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
 #endif
   const int SAMPLE = CC_KNN_SAMPLE;
   const int m = (3 * k + 7) / 8 > 16 ? (3 * k + 7) / 8 : 16;
-  const bool sampled = !g_force_route_a && NB >= 64 * SAMPLE && N >= (int64_t)64 * SAMPLE * m && k <= 50;
+  // Route 1a pays ~50 us per block while its lists fill (every block overflows them), 1-4 ms even at
+  // N = 1000; 1b has no such phase, so it takes everything from 8 sampled blocks up, and inputs that
+  // fit the collect buffer whole skip the sample (T = +inf: every candidate is listed).
+#ifndef CC_KNN_MIN_SBLK
+#define CC_KNN_MIN_SBLK 1
+#endif
   const int col_cap = 4 * SAMPLE * m;   // collect buffer entries per query
+  const bool collect_all = !g_force_route_a && k <= 50 && N <= col_cap;
+  const bool sampled = collect_all || (!g_force_route_a && NB >= CC_KNN_MIN_SBLK * SAMPLE &&
+                                       N >= (int64_t)CC_KNN_MIN_SBLK * SAMPLE * m && k <= 50);
 
   static DevBuf P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
       bnd_d, bnd_i, partial, mu;
@@ -1246,12 +1259,17 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
         while (SS > 1 && NBss / SAMPLE < 4 * m) { --SS; NBss = ceil_div(NB, SS); }   // keep >= 4m sampled blocks per range
         if (SS == 1) NBss = NB;
       }
-      if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS) * (size_t)SS))) return rc;
-      if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q * (size_t)SS))) return rc;
       if ((rc = Tq.alloc(sizeof(float) * (size_t)n_q))) return rc;
-      if ((rc = run_select(NG, sa, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) return rc;
-      hipLaunchKernelGGL(knn_threshold_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(),
-                         skeys.as<u64>(), scnts.as<int>(), n_q, SS, KPS, m, Tq.as<float>());
+      if (collect_all) {
+        hipLaunchKernelGGL(knn_fill_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(), Tq.as<float>(),
+                           n_q, INFINITY);
+      } else {
+        if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS) * (size_t)SS))) return rc;
+        if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q * (size_t)SS))) return rc;
+        if ((rc = run_select(NG, sa, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) return rc;
+        hipLaunchKernelGGL(knn_threshold_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(),
+                           skeys.as<u64>(), scnts.as<int>(), n_q, SS, KPS, m, Tq.as<float>());
+      }
       // 1b-ii: collect over all candidates, 8 splits (one per XCD) or fewer for short scans
       make_splits(NB, 8, &S, &NBs);
       if ((rc = cbuf.alloc(sizeof(u64) * (size_t)n_q * (size_t)col_cap))) return rc;

@@ -35,6 +35,22 @@ def test_shapes_and_dims(hip, oracle_built, n, d, k):
     check(x, k)
 
 
+@pytest.mark.parametrize('n,d,k', [(300, 64, 15), (512, 8, 50), (513, 8, 50), (1000, 64, 15), (2048, 3, 33), (6000, 64, 15)])
+def test_small_inputs_both_routes(hip, oracle_built, n, d, k):
+    # small inputs take the collect route too (without the sample when they fit the collect buffer whole);
+    # the full select (stage 1a) must give the same bits
+    rng = np.random.default_rng(n * 7 + d + k)
+    x = rng.random((n, d), dtype=np.float32)
+    x[rng.choice(n, n // 10, replace=False)] = x[rng.choice(n, n // 10)]
+    idx = check(x, k)
+    hipknn.force_full_select(True)
+    try:
+        idx_a = check(x, k)
+    finally:
+        hipknn.force_full_select(False)
+    assert np.array_equal(idx, idx_a)
+
+
 def test_include_self_and_signed_data(hip, oracle_built):
     x = np.random.default_rng(3).standard_normal((1500, 24)).astype(np.float32) * 3
     idx = check(x, 15, include_self=True)

@@ -13,6 +13,8 @@ k = int(sys.argv[3]) if len(sys.argv) > 3 else 15
 nq = int(sys.argv[4]) if len(sys.argv) > 4 else n
 reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 _lib.ensure_init(0)
+if os.environ.get('CC_FULL'):
+    _lib.lib().cc_knn_force_full_select(1)   # route 1a whatever the size
 x = torch.rand((n, d), device='cuda'); torch.cuda.synchronize()
 knn_graph_device(x.data_ptr(), n, d, k, 0, nq)
 _lib.profile_enable(True); _lib.profile_reset()
