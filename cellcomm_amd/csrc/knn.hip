@@ -1171,8 +1171,9 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   const int64_t NB = ceil_div(N, 32);
   const int64_t tiles = ceil_div(n_q, 32);
 
-  // Route 1b (sampled threshold + collect) for large candidate sets and moderate k; route 1a
-  // (full select with running threshold) otherwise.  Sample = every 8th candidate block, T = the
+  // Route 1b (sampled threshold + collect) is the product route; route 1a (full select with a running
+  // threshold) remains for inputs below 8 sampled blocks that do not fit the collect buffer (none with
+  // the default knobs) and as the cross-check behind cc_knn_force_full_select.  Sample = every 8th candidate block, T = the
   // m-th best of the sample (m = max(16, 3k/8)): the number of candidates below T is ~Gamma(m)·8, i.e.
   // 8m >= 3k on average, >= k and <= 4·8m except with probability < 1e-4 per query; either miss only
   // sends that query to the float64 fallback.
@@ -1188,9 +1189,12 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
 #define CC_KNN_MIN_SBLK 1
 #endif
   const int col_cap = 4 * SAMPLE * m;   // collect buffer entries per query
-  const bool collect_all = !g_force_route_a && k <= 50 && N <= col_cap;
+#ifndef CC_KNN_SAMPLED_MAXK
+#define CC_KNN_SAMPLED_MAXK 128
+#endif
+  const bool collect_all = !g_force_route_a && k <= CC_KNN_SAMPLED_MAXK && N <= col_cap;
   const bool sampled = collect_all || (!g_force_route_a && NB >= CC_KNN_MIN_SBLK * SAMPLE &&
-                                       N >= (int64_t)CC_KNN_MIN_SBLK * SAMPLE * m && k <= 50);
+                                       N >= (int64_t)CC_KNN_MIN_SBLK * SAMPLE * m && k <= CC_KNN_SAMPLED_MAXK);
 
   static DevBuf P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
       bnd_d, bnd_i, partial, mu;

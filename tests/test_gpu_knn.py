@@ -35,7 +35,8 @@ def test_shapes_and_dims(hip, oracle_built, n, d, k):
     check(x, k)
 
 
-@pytest.mark.parametrize('n,d,k', [(300, 64, 15), (512, 8, 50), (513, 8, 50), (1000, 64, 15), (2048, 3, 33), (6000, 64, 15)])
+@pytest.mark.parametrize('n,d,k', [(300, 64, 15), (512, 8, 50), (513, 8, 50), (1000, 64, 15), (2048, 3, 33), (6000, 64, 15),
+                                   (1200, 40, 64), (1537, 16, 128), (5000, 64, 128)])
 def test_small_inputs_both_routes(hip, oracle_built, n, d, k):
     # small inputs take the collect route too (without the sample when they fit the collect buffer whole);
     # the full select (stage 1a) must give the same bits
