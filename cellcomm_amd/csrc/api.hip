@@ -381,7 +381,8 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
     e->tail_rows = n;
   }
   if (dual) CC_HIP(hipStreamSynchronize(g_stream));   // workspace / h2_all memsets are on the library stream
-  struct StreamReset { ~StreamReset() { g_cur = nullptr; } } stream_reset;
+  struct StreamReset { ~StreamReset() { g_cur = nullptr; g_gemm_pace = false; } } stream_reset;
+  g_gemm_pace = !dual;
   static hipEvent_t lead_done = nullptr;
   if (lead_passes > 0 && !lead_done) CC_HIP(hipEventCreateWithFlags(&lead_done, hipEventDisableTiming));
   int64_t pass_no = 0;

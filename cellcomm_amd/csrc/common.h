@@ -79,6 +79,7 @@ void free_weight(PackedWeight *w);
 // lda* must cover KT*·BK columns and the columns beyond K* must be zero.
 int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M,
                 const PackedWeight &W, float *C, int64_t ldc, int act, int prof_class);
+extern bool g_gemm_pace;   // workgroup pacing of layers 1-2 (gemm.hip); only while one GEMM runs at a time
 int launch_row_softmax(float *X, int64_t M, int E, int64_t ld);
 
 // gemm16.hip — layers 1/2 on the fp16 matrix cores (CC_DTYPE_F16 / CC_DTYPE_F16X2)

@@ -51,6 +51,25 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define CC_GEMM_DBUF 0
 #endif
 
+// CC_GEMM_PACE=1 (experiment, off): workgroups that share panels are kept within a few K-steps of each
+// other (chunks of CC_GEMM_PACE_EVERY K-steps, at most CC_GEMM_PACE_LEAD + 1 chunks ahead of the slowest
+// member).  Measured on layer 1 (tools/pace_sweep.sh, tools/pmc_collect.sh): L2 hit rate 29 % -> 62 % (EVERY=8)
+// / 81 % (EVERY=2), L2-miss traffic 33 -> 17.9 / 8.9 GB per launch, but 137.4 -> 134.7 / 128.5 TFLOP/s:
+// the misses are served on-die and are not on the critical path, while lock-step issue is slower.
+#ifndef CC_GEMM_PACE
+#define CC_GEMM_PACE 0
+#endif
+#ifndef CC_GEMM_PACE_EVERY
+#define CC_GEMM_PACE_EVERY 4
+#endif
+#ifndef CC_GEMM_PACE_LEAD
+#define CC_GEMM_PACE_LEAD 2
+#endif
+#ifndef CC_GEMM_PACE_BUDGET
+#define CC_GEMM_PACE_BUDGET 8192      // polls (~0.25 us each) a workgroup may spend waiting, in total
+#endif
+bool g_gemm_pace = false;             // set by the encoder around single-stream calls
+
 constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
 constexpr int LDS_A_STRIDE = BK + 4;            // floats; (BK+4)·r mod 64 distinct for r mod 16
 constexpr int GEMM_THREADS = 256;
@@ -67,6 +86,11 @@ static_assert(BN == 128 && (BK == 32 || BK == 64), "tile shape");
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
+#ifdef CC_GEMM_TRACE
+// diagnostic build only (tools/gemm_trace.py): per-workgroup wall-clock stamps of the layer-1 kernel
+__device__ unsigned long long g_gemm_trace[16384 * 4];
+#endif
+
 // KCLASS only names the instantiation (so profilers tell layer 1 / layer 2 / tail apart).
 template <int KCLASS>
 __global__
@@ -78,7 +102,7 @@ __launch_bounds__(GEMM_THREADS)
 void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const float *__restrict__ A2,
                           int64_t lda2, int64_t M, const f32x4 *__restrict__ Wp,
                           const float *__restrict__ bias, int KT1, int KT, int N, int MT, int NT,
-                          float *__restrict__ C, int64_t ldc, int act) {
+                          float *__restrict__ C, int64_t ldc, int act, int *__restrict__ pace, int pace_nch) {
   constexpr int STAGE_FLOATS = BM * LDS_A_STRIDE + TILE_W_FLOAT4 * 4;
   __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS * (CC_GEMM_DBUF ? 2 : 1)];
   float *As = lds;
@@ -96,11 +120,38 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   const int n_tile = (wgid % per_group) / gsz;
   const int64_t m0 = (int64_t)m_tile * BM;
   const int n0 = n_tile * BN;
+#if CC_GEMM_PACE
+  // Pacing group = the 32 workgroups dispatched back to back to this XCD (one per CU): the CU's wave
+  // arbiter serves its oldest workgroup first, so these advance through K at the same rate while the
+  // three workgroups sharing a CU do not (measured: K/2 reached at 1.95 / 3.08 / 3.29 ms).  Keeping a
+  // group within a few K-steps keeps its A/W panels (8 m-tiles x 4 n-tiles) in the XCD's L2.  Waiting is
+  // bounded (poll budget), so a group member that is not resident costs time, never progress.
+  int *pace_grp = nullptr;
+  int pace_size = 0, pace_budget = CC_GEMM_PACE_BUDGET, pace_seen = 0;
+  if (pace) {
+    const int n_local = q + (xcd < rem ? 1 : 0), j = bid >> 3;
+    const int grp = j >> 5;
+    pace_size = 64 * (n_local - 32 * grp < 32 ? n_local - 32 * grp : 32);   // every member adds 64 per chunk
+    pace_grp = pace + ((int64_t)xcd * ((q + 32) >> 5) + grp) * pace_nch;
+  }
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
+#if CC_GEMM_PACE
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#endif
+#ifdef CC_GEMM_TRACE
+  if (KCLASS == 1 && tid == 0 && bid < 16384) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_gemm_trace[4 * bid + 0] = wall_clock64();
+    g_gemm_trace[4 * bid + 3] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 
   // ---- staging: per-thread running pointers into A (re-based once at the
   //      segment switch) and a scalar running pointer into the packed W tiles ----
@@ -123,7 +174,12 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
 
   // The staging registers must stay in VGPRs (hipcc demotes them to scratch when
   // they are touched through lambdas or selected between arrays) so that the
-  // loads stay in flight behind the MFMAs of the current K-step.
+  // loads stay in flight behind the MFMAs of the current K-step.  Register assignment
+  // matters too: with `tid` and one more per-lane value alive across the K loop the
+  // allocator moved the accumulators from v[0:15].. to v[2:17].. (and the A/B operands
+  // with them) and the same instruction stream ran 11 % slower (137 -> 123 TFLOP/s), so
+  // the accumulators are pinned below.  (The fp16 and kNN kernels did not react to the
+  // same pin: tools/pin_sweep.sh.)
   f32x4 ra[NA], rb[NB];
 
   f32x16 acc[2][2];
@@ -133,6 +189,11 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+  // pin the four accumulator tuples where the fast build has them (see the note above)
+  asm volatile("" : "+{v[0:15]}"(acc[1][1]));
+  asm volatile("" : "+{v[16:31]}"(acc[0][1]));
+  asm volatile("" : "+{v[32:47]}"(acc[1][0]));
+  asm volatile("" : "+{v[48:63]}"(acc[0][0]));
 
   if (KT > 0) {
 #pragma unroll
@@ -197,8 +258,35 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
 #pragma unroll
       for (int p = 0; p < NB; ++p) Bs4[tid + p * GEMM_THREADS] = rb[p];
     }
+#if CC_GEMM_PACE
+    // wave 0 as a whole (wave-uniform control flow, scalar state: nothing per-lane stays live across
+    // the K loop): its 64 lanes' atomic adds are merged into one +64 by the compiler
+    if (pace_grp && wave_u == 0 && (kt + 1) % CC_GEMM_PACE_EVERY == 0) {
+      const int c = (kt + 1) / CC_GEMM_PACE_EVERY - 1;
+      // the counter this boundary depends on was read one boundary ago (pace_seen: a whole chunk for the
+      // load to return), so a group that is in step never waits for memory here; nothing of this wave
+      // is in flight at this point, so consuming pace_seen does not wait for the atomic below either
+      if (c >= CC_GEMM_PACE_LEAD && __builtin_amdgcn_readfirstlane(pace_seen) < pace_size) {
+        const int *w = pace_grp + c - CC_GEMM_PACE_LEAD;
+        while (pace_budget > 0 &&
+               __builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < pace_size) {
+          __builtin_amdgcn_s_sleep(8);
+          --pace_budget;
+        }
+      }
+      __hip_atomic_fetch_add(pace_grp + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c + 1 >= CC_GEMM_PACE_LEAD)
+        pace_seen = __hip_atomic_load(pace_grp + c + 1 - CC_GEMM_PACE_LEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
     __syncthreads();
+#ifdef CC_GEMM_TRACE
+    if (KCLASS == 1 && tid == 0 && bid < 16384 && kt == KT / 2) g_gemm_trace[4 * bid + 1] = wall_clock64();
+#endif
   }
+#ifdef CC_GEMM_TRACE
+  if (KCLASS == 1 && tid == 0 && bid < 16384) g_gemm_trace[4 * bid + 2] = wall_clock64();
+#endif
 
 #else
   int cur = 0;
@@ -355,11 +443,31 @@ int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, in
   const int64_t MT = ceil_div(M, BM);
   const int64_t nwg = MT * W.NT;
   CC_REQUIRE(nwg < (int64_t)2147483647, "gemm: grid too large");
+  // pacing counters: [8 XCDs][groups of 32 workgroups][chunks of K-steps], zeroed per launch
+  int *pace = nullptr;
+  int pace_nch = 0;
+#if CC_GEMM_PACE && !CC_GEMM_DBUF
+  static int *pace_buf = nullptr;
+  static size_t pace_cap = 0;
+  if (g_gemm_pace && prof_class != CC_PROF_GEMM_TAIL && nwg >= 512) {
+    pace_nch = (int)ceil_div(W.KT1 + W.KT2, CC_GEMM_PACE_EVERY);
+    const size_t need = sizeof(int) * 8 * (size_t)(((nwg >> 3) + 32) >> 5) * (size_t)pace_nch;
+    if (need > pace_cap) {
+      if (pace_buf) (void)hipFree(pace_buf);
+      pace_buf = nullptr;
+      pace_cap = 0;
+      CC_HIP(hipMalloc(&pace_buf, need));
+      pace_cap = need;
+    }
+    CC_HIP(hipMemsetAsync(pace_buf, 0, need, stream()));
+    pace = pace_buf;
+  }
+#endif
   ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
 #define CC_LAUNCH_GEMM(KC)                                                                                  \
   hipLaunchKernelGGL(gemm_bias_act_kernel<KC>, dim3((unsigned)nwg), dim3(GEMM_THREADS), 0, stream(), A1,    \
                      lda1, A2, lda2, M, reinterpret_cast<const f32x4 *>(W.d_w), W.d_bias, (int)W.KT1,     \
-                     (int)(W.KT1 + W.KT2), (int)W.N, (int)MT, (int)W.NT, C, ldc, act)
+                     (int)(W.KT1 + W.KT2), (int)W.N, (int)MT, (int)W.NT, C, ldc, act, pace, pace_nch)
   if (prof_class == CC_PROF_GEMM_L1) CC_LAUNCH_GEMM(1);
   else if (prof_class == CC_PROF_GEMM_L2) CC_LAUNCH_GEMM(2);
   else CC_LAUNCH_GEMM(3);
@@ -367,6 +475,15 @@ int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, in
   CC_HIP(hipGetLastError());
   return CC_OK;
 }
+
+#ifdef CC_GEMM_TRACE
+}  // namespace cc
+extern "C" int cc_debug_gemm_trace(unsigned long long *out, int n_wg) {
+  CC_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(cc::g_gemm_trace), sizeof(unsigned long long) * 4 * (size_t)n_wg));
+  return CC_OK;
+}
+namespace cc {
+#endif
 
 // ---- row softmax (classify encoder's last activation,
 //      reference src/bigan_classify.py:39) ------------------------------------
