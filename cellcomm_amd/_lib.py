@@ -64,6 +64,8 @@ SIGNATURES = {
     'cc_knn_force_full_select': (c_int, [c_int]),
     'cc_knn_use_fp16_collect': (c_int, [c_int]),
     'cc_knn_last_fallback_count': (c_int64, []),
+    'cc_knn_use_fp64_prefilter': (c_int, [c_int]),
+    'cc_knn_last_full_scan_count': (c_int64, []),
     'cc_duplicate_representatives': (c_int, [c_void_p, c_int64, c_void_p]),
     'cc_profile_enable': (c_int, [c_int]),
     'cc_profile_reset': (c_int, []),

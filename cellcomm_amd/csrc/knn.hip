@@ -42,7 +42,9 @@ using u64 = unsigned long long;
 static bool g_force_fallback = false;
 static bool g_force_route_a = false;  // test hook: always take the full-select route
 static bool g_use_fp16_collect = true; // stage 1b collect on the fp16 matrix cores when the data's scale allows
+static bool g_use_fp64_prefilter = true; // stage 3: float64 matrix-core prefilter in front of the exact scan
 static int64_t g_last_fallback = 0;
+static int64_t g_last_full_scan = 0;     // fallback queries that had to scan every candidate in float64 VALU
 
 __device__ __forceinline__ unsigned f32_to_ordered(float f) {
   unsigned b = __float_as_uint(f);
@@ -853,7 +855,7 @@ __global__ void knn_threshold_kernel(const u64 *__restrict__ skeys, const int *_
 // lists; route 1b: S = 1, the collect buffer, whose cursor may exceed lcap = overflow).  Output:
 // keys[q][0..c) sorted, cnts[q] = c = min(total, KP) and bound[q] = the approximate distance
 // below which EVERY candidate is in keys[q] (+inf: all admissible candidates are listed).
-// A query whose buffer overflowed or holds fewer than k keys goes straight to the fallback.
+// A query that holds fewer than k keys goes straight to the fallback.
 __global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ skeys, const int *__restrict__ scnt,
                                                         const float *__restrict__ T, int64_t n_q, int S, int lcap,
                                                         int KP, int k, u64 *__restrict__ keys, int *__restrict__ cnts,
@@ -876,7 +878,10 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ 
   }
   const float Tq = T ? T[ql] : INFINITY;   // route 1b: nothing above T was collected
   if (T && Tq < INFINITY) all_listed = false;
-  if (overflow || c < k) {
+  // too few keys: nothing to bound the search with, the query takes the full float64 scan.  An overflowed
+  // buffer still yields K' real candidates: stage 2 turns them into an exact (if loose) bound for stage 3,
+  // and bound = -inf keeps it from certifying them.
+  if (c < k) {
     if (lane == 0) {
       const int pos = atomicAdd(nflag, 1);
       flagged[pos] = (int)ql;
@@ -892,11 +897,11 @@ __global__ __launch_bounds__(256) void knn_merge_kernel(const u64 *__restrict__ 
     int rk = 0;
     for (int i = 0; i < c; ++i) rk += (buf[i] < e) ? 1 : 0;
     if (rk < KP) keys[ql * KP + rk] = e;
-    if (rk == KP - 1) bound[ql] = fminf(ordered_to_f32((unsigned)(e >> 32)), Tq);
+    if (rk == KP - 1) bound[ql] = overflow ? -INFINITY : fminf(ordered_to_f32((unsigned)(e >> 32)), Tq);
   }
   if (lane == 0) {
     cnts[ql] = c < KP ? c : KP;
-    if (c < KP) bound[ql] = all_listed ? INFINITY : Tq;
+    if (c < KP) bound[ql] = overflow ? -INFINITY : (all_listed ? INFINITY : Tq);
   }
 }
 
@@ -974,7 +979,8 @@ constexpr int FB_PER_THREAD = FB_CAP / FB_THREADS;
 __global__ __launch_bounds__(FB_THREADS) void knn_exact_scan_kernel(
     const float *__restrict__ x, int64_t N, int d, int64_t q_begin, const int *__restrict__ flagged,
     const double *__restrict__ bound_d, const int *__restrict__ bound_i, int k, int include_self,
-    int32_t *__restrict__ out_idx, float *__restrict__ out_dist) {
+    int32_t *__restrict__ out_idx, float *__restrict__ out_dist, const int *__restrict__ list,
+    const int *__restrict__ list_cnt, int list_cap, int *__restrict__ n_full) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   double *bd = reinterpret_cast<double *>(smem);         // [FB_CAP]
   double *xq = bd + FB_CAP;                              // [d]
@@ -1032,8 +1038,18 @@ __global__ __launch_bounds__(FB_THREADS) void knn_exact_scan_kernel(
     __syncthreads();
   };
 
-  for (int64_t base = 0; base < N; base += FB_THREADS) {
-    const int64_t cand = base + tid;
+  // with a prefilter list (stage 3a) only the listed candidates are evaluated: the list holds every
+  // candidate whose float64 distance can be <= the bound, so the outcome is that of the full scan
+  const int *my_list = nullptr;
+  int64_t n_scan = N;
+  if (list) {
+    const int lc = list_cnt[blockIdx.x];
+    if (lc <= list_cap) { my_list = list + (int64_t)blockIdx.x * list_cap; n_scan = lc; }
+  }
+  if (!my_list && n_full && tid == 0) atomicAdd(n_full, 1);
+  for (int64_t base = 0; base < n_scan; base += FB_THREADS) {
+    const int64_t pos = base + tid;
+    const int64_t cand = pos < n_scan ? (my_list ? (int64_t)my_list[pos] : pos) : N;
     if (cand < N && (include_self || cand != q)) {
       const double dist = exact_dist(xq, x + cand * d, d);
       const double bdv = s_bound_d;
@@ -1048,6 +1064,119 @@ __global__ __launch_bounds__(FB_THREADS) void knn_exact_scan_kernel(
     if (s_cnt > FB_CAP - FB_THREADS) compact(false);  // uniform: s_cnt read after the barrier
   }
   compact(true);
+}
+
+// ---- stage 3a: float64 matrix-core prefilter for the queries stage 2 could not certify -------------
+// Tight clusters in many dimensions (all neighbours nearly equidistant, far from the centroid) defeat
+// the fp32/fp16 certificate for EVERY query, and the exact scan re-reads all candidates per query
+// (100k x 100k: 410 ms, bound by 2.5 TB of L2/Infinity-Cache reads).  Here 16 flagged queries share
+// each candidate block through v_mfma_f64_16x16x4_f64: D[cand][query] = |c|^2 + |q|^2 - 2 q.c in
+// float64 (error ~1e-14 of the norms), and every candidate at or below the query's bound (the exact
+// k-th distance stage 2 found, so an upper bound of the true one) plus that error goes to a short
+// list; the exact scan then evaluates the oracle's expression on the list only.
+// K-slot map (any permutation works as long as A and B agree): step 4u + t, lane group g = lane / 16
+// <-> dimension 16u + 4g + t, so a lane's 4 steps of superchunk u are one 16-byte load.
+using f64x4 = __attribute__((ext_vector_type(4))) double;
+using f32x4v = __attribute__((ext_vector_type(4))) float;
+
+__global__ void knn_norm64_kernel(const float *__restrict__ x, int64_t N, int d, double *__restrict__ norm64,
+                                  unsigned long long *__restrict__ max_bits) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  double s = 0.0;
+  if (i < N)
+    for (int t = 0; t < d; ++t) { const double v = (double)x[i * d + t]; s += v * v; }
+  if (i < N) norm64[i] = s;
+  // non-negative doubles order like their bit patterns
+  unsigned long long b = (i < N && s == s) ? (unsigned long long)__double_as_longlong(s) : 0ull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const unsigned long long ob = __shfl_xor(b, o); b = ob > b ? ob : b; }
+  if ((threadIdx.x & 63) == 0) atomicMax(max_bits, b);
+}
+
+__device__ __forceinline__ f32x4v ld4_dims(const float *__restrict__ row, int k0, int d, bool vec) {
+  f32x4v v = {0.f, 0.f, 0.f, 0.f};
+  if (vec) {
+    if (k0 < d) v = *reinterpret_cast<const f32x4v *>(row + k0);   // d % 4 == 0: the chunk is inside or outside
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (k0 + t < d) v[t] = row[k0 + t];
+  }
+  return v;
+}
+
+template <int ND>
+__global__ __launch_bounds__(64) void knn_prefilter64_kernel(
+    const float *__restrict__ x, const double *__restrict__ norm64, const unsigned long long *__restrict__ max_bits,
+    int64_t N, int d, int vec, int64_t q_begin, const int *__restrict__ flagged, int nflag,
+    const double *__restrict__ bound_d, double eps_coef, int include_self, int S, int64_t NBs, int cap,
+    int *__restrict__ list, int *__restrict__ list_cnt) {
+  const int lane = threadIdx.x, j = lane & 15, g = lane >> 4;
+  const int64_t tile = blockIdx.x / S;
+  const int split = blockIdx.x % S;
+  const int64_t NB = (N + 15) >> 4;
+  const int64_t b_lo = split * NBs, b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
+  const int64_t f = tile * 16 + j;
+  const bool fvalid = f < nflag;
+  const int64_t ql = fvalid ? flagged[f] : 0;
+  const int64_t q = q_begin + ql;
+  // threshold: the bound, widened by what the two float64 evaluations can differ
+  double T = -INFINITY;
+  if (fvalid) {
+    const double b = bound_d[ql];
+    if (b < INFINITY) {
+      T = b * (1.0 + (double)(d + 4) * 2.220446049250313e-16) +
+          eps_coef * (norm64[q] + __longlong_as_double((long long)*max_bits));
+    } else if (split == 0 && g == 0) {
+      list_cnt[f] = cap + 1;   // no finite bound: this query takes the full scan
+    }
+  }
+  double bq[4 * ND];
+#pragma unroll
+  for (int u = 0; u < ND; ++u) {
+    const f32x4v v = ld4_dims(x + q * d, 16 * u + 4 * g, d, vec != 0);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bq[4 * u + t] = fvalid ? -2.0 * (double)v[t] : 0.0;
+  }
+  const double bn = g == 0 ? 1.0 : (g == 1 ? (fvalid ? norm64[q] : 0.0) : 0.0);
+
+  f32x4v cur[ND], nxt[ND];
+  {
+    int64_t c = b_lo * 16 + j;
+    c = c < N ? c : N - 1;
+#pragma unroll
+    for (int u = 0; u < ND; ++u) cur[u] = ld4_dims(x + c * d, 16 * u + 4 * g, d, vec != 0);
+  }
+  for (int64_t b = b_lo; b < b_hi; ++b) {
+    int64_t cl = b * 16 + j;
+    cl = cl < N ? cl : N - 1;
+    {
+      int64_t cn = (b + 1 < b_hi ? b + 1 : b) * 16 + j;
+      cn = cn < N ? cn : N - 1;
+#pragma unroll
+      for (int u = 0; u < ND; ++u) nxt[u] = ld4_dims(x + cn * d, 16 * u + 4 * g, d, vec != 0);
+    }
+    const double an = g == 0 ? norm64[cl] : (g == 1 ? 1.0 : 0.0);
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < ND; ++u)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64((double)cur[u][t], bq[4 * u + t], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(an, bn, acc, 0, 0, 0);
+    // f64 16x16x4 result layout (probed: tools/experiments/mfma_f64_layout.hip): register r of lane
+    // (j, g) is D[4r + g][j] - NOT the 4g + r of the f32 16x16 shapes - i.e. candidate 16b + 4r + g
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t cand = b * 16 + 4 * r + g;
+      if (acc[r] <= T && cand < N && (include_self || cand != q)) {
+        const int pos = atomicAdd(&list_cnt[f], 1);
+        if (pos < cap) list[f * cap + pos] = (int)cand;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < ND; ++u) cur[u] = nxt[u];
+  }
 }
 
 // ---- host orchestration ----------------------------------------------------------------------
@@ -1181,7 +1310,11 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
 #define CC_KNN_SAMPLE 8
 #endif
   const int SAMPLE = CC_KNN_SAMPLE;
-  const int m = (3 * k + 7) / 8 > 16 ? (3 * k + 7) / 8 : 16;
+#ifndef CC_KNN_MIN_M
+#define CC_KNN_MIN_M (128 / CC_KNN_SAMPLE)   // 16 at SAMPLE = 8: m >= k for k <= 16, so the sampled points alone fill the list
+#endif
+  const int m_min = CC_KNN_MIN_M, m_k = (3 * k + SAMPLE - 1) / SAMPLE;   // SAMPLE·m >= max(128, 3k) expected below T
+  const int m = m_k > m_min ? m_k : m_min;
   // Route 1a pays ~50 us per block while its lists fill (every block overflows them), 1-4 ms even at
   // N = 1000; 1b has no such phase, so it takes everything from 8 sampled blocks up, and inputs that
   // fit the collect buffer whole skip the sample (T = +inf: every candidate is listed).
@@ -1352,13 +1485,62 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   CC_HIP(hipMemcpyAsync(&h_nflag, nflag.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
   CC_HIP(hipStreamSynchronize(stream()));
   g_last_fallback = h_nflag;
+  g_last_full_scan = 0;
   if (h_nflag > 0) {
     const size_t lds = sizeof(double) * (size_t)(FB_CAP + d + 1) + sizeof(int) * (size_t)(FB_CAP + 2);
     ProfScope prof(CC_PROF_KNN_FALLBACK, 3.0 * (double)h_nflag * (double)N * (double)d);
+    const int *d_list = nullptr, *d_list_cnt = nullptr;
+    const int list_cap = 4096;
+    static DevBuf norm64, max64, plist, pcnt, nfull;
+    if ((rc = nfull.alloc(16))) return rc;
+    CC_HIP(hipMemsetAsync(nfull.p, 0, 16, stream()));
+    if (g_use_fp64_prefilter && N >= 2048) {
+      // 3a: float64 matrix-core prefilter, 16 flagged queries per wave
+      int ND64 = 0;
+      for (int o : {1, 2, 4, 9})
+        if (16 * o >= d) { ND64 = o; break; }
+      if ((rc = norm64.alloc(sizeof(double) * (size_t)N))) return rc;
+      if ((rc = max64.alloc(16))) return rc;
+      if ((rc = plist.alloc(sizeof(int) * (size_t)h_nflag * (size_t)list_cap))) return rc;
+      if ((rc = pcnt.alloc(sizeof(int) * (size_t)h_nflag))) return rc;
+      CC_HIP(hipMemsetAsync(max64.p, 0, 16, stream()));
+      CC_HIP(hipMemsetAsync(pcnt.p, 0, sizeof(int) * (size_t)h_nflag, stream()));
+      hipLaunchKernelGGL(knn_norm64_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, stream(), d_x, N, d,
+                         norm64.as<double>(), max64.as<unsigned long long>());
+      const int64_t NB16 = ceil_div(N, 16), qtiles = ceil_div(h_nflag, 16);
+      int S64 = (int)ceil_div(8192, qtiles);              // enough waves for ~2 rounds over the chip
+      if (S64 > NB16 / 64) S64 = (int)(NB16 / 64);        // but scans of at least 64 blocks each
+      if (S64 < 1) S64 = 1;
+      const int64_t NBs64 = ceil_div(NB16, S64);
+      S64 = (int)ceil_div(NB16, NBs64);
+      // the two float64 evaluations differ by <= (16·ND + d + 8) roundings of terms that sum to <= 2(|q|^2 + |c|^2)
+      const double eps64 = 4.0 * (16.0 * ND64 + (double)d + 8.0) * 1.1102230246251565e-16;
+      const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(d_x) & 15) == 0) ? 1 : 0;
+#define CC_PF64(NDV)                                                                                              \
+  case NDV:                                                                                                       \
+    hipLaunchKernelGGL(knn_prefilter64_kernel<NDV>, dim3((unsigned)(qtiles * S64)), dim3(64), 0, stream(), d_x,    \
+                       norm64.as<double>(), max64.as<unsigned long long>(), N, d, vec, q_begin, flagged.as<int>(), \
+                       h_nflag, bnd_d.as<double>(), eps64, include_self, S64, NBs64, list_cap, plist.as<int>(),    \
+                       pcnt.as<int>());                                                                            \
+    break;
+      switch (ND64) {
+        CC_PF64(1) CC_PF64(2) CC_PF64(4) CC_PF64(9)
+        default: CC_REQUIRE(false, "knn: no float64 prefilter for d=%d", d);
+      }
+#undef CC_PF64
+      CC_HIP(hipGetLastError());
+      d_list = plist.as<int>();
+      d_list_cnt = pcnt.as<int>();
+    }
+    // 3b: the oracle's expression on the listed candidates (or on all of them without a usable list)
     hipLaunchKernelGGL(knn_exact_scan_kernel, dim3((unsigned)h_nflag), dim3(FB_THREADS), lds, stream(), d_x, N, d,
                        q_begin, flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>(), k, include_self,
-                       oidx.as<int32_t>(), odist.as<float>());
+                       oidx.as<int32_t>(), odist.as<float>(), d_list, d_list_cnt, list_cap, nfull.as<int>());
     CC_HIP(hipGetLastError());
+    int h_full = 0;
+    CC_HIP(hipMemcpyAsync(&h_full, nfull.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
+    CC_HIP(hipStreamSynchronize(stream()));
+    g_last_full_scan = h_full;
   }
   CC_HIP(hipMemcpyAsync(h_idx, oidx.p, sizeof(int32_t) * (size_t)(n_q * k), hipMemcpyDeviceToHost, stream()));
   CC_HIP(hipMemcpyAsync(h_dist, odist.p, sizeof(float) * (size_t)(n_q * k), hipMemcpyDeviceToHost, stream()));
@@ -1373,6 +1555,11 @@ extern "C" int cc_knn_force_fallback(int on) {
   return CC_OK;
 }
 extern "C" int64_t cc_knn_last_fallback_count(void) { return cc::g_last_fallback; }
+extern "C" int64_t cc_knn_last_full_scan_count(void) { return cc::g_last_full_scan; }
+extern "C" int cc_knn_use_fp64_prefilter(int on) {
+  cc::g_use_fp64_prefilter = on != 0;
+  return CC_OK;
+}
 extern "C" int cc_knn_use_fp16_collect(int on) {
   cc::g_use_fp16_collect = on != 0;
   return CC_OK;

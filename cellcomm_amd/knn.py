@@ -61,3 +61,14 @@ def force_full_select(on):
 def use_fp16_collect(on):
     """Stage 1b collect pass on the fp16 (default) or fp32 matrix cores; same results, different speed."""
     _lib.check(_lib.lib().cc_knn_use_fp16_collect(1 if on else 0))
+
+
+def use_fp64_prefilter(on):
+    """Stage 3: narrow each uncertified query's candidates with a float64 matrix-core pass (default) before
+    the exact evaluation, or scan all candidates; same results, different speed."""
+    _lib.check(_lib.lib().cc_knn_use_fp64_prefilter(1 if on else 0))
+
+
+def last_full_scan_count():
+    """Uncertified queries of the last call that had to scan every candidate in float64."""
+    return int(_lib.lib().cc_knn_last_full_scan_count())

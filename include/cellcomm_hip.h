@@ -154,8 +154,14 @@ int cc_knn_force_fallback(int on);
 int cc_knn_use_fp16_collect(int on);
 /* Test hook: disable the sampled-threshold route of stage 1 (always full select). */
 int cc_knn_force_full_select(int on);
-/* Queries of the last cc_knn_* call that needed the float64 fallback scan. */
+/* Queries of the last cc_knn_* call that stage 2 could not certify (they are re-done in float64). */
 int64_t cc_knn_last_fallback_count(void);
+/* Stage 3 first narrows each uncertified query's candidates with a float64 matrix-core pass
+ * (default on); off = every such query scans all candidates.  Results are identical. */
+int cc_knn_use_fp64_prefilter(int on);
+/* Of those, the queries that had to scan ALL candidates in float64 (no finite bound from stage 2,
+ * or more than 4096 candidates under it). */
+int64_t cc_knn_last_full_scan_count(void);
 
 /* ---- duplicate coordinates: the `ds` field of an encits document
  *      (reference src/intercepts/db_recorder.py:113-117, O(N·U) there) ------------- */

@@ -71,6 +71,33 @@ def test_heavy_duplicates_need_the_fallback(hip, oracle_built):
     check(x3, 50)
 
 
+@pytest.mark.parametrize('d,k,csize,spread', [(64, 15, 500, 0.01), (64, 15, 40, 0.3), (30, 33, 100, 0.02), (7, 15, 300, 1e-3),
+                                               (132, 5, 64, 0.05)])
+def test_tight_sorted_clusters_take_the_float64_prefilter(hip, oracle_built, d, k, csize, spread):
+    # all neighbours nearly equidistant and far from the centroid: the fp32/fp16 certificate fails for most
+    # queries; stage 3a (float64 matrix-core prefilter) must leave only short candidate lists, and the result
+    # must equal the oracle's and the one obtained with every uncertified query scanning all candidates
+    n = 6000
+    rng = np.random.default_rng(d * 1000 + k)
+    nc = n // csize
+    centres = rng.random((nc, d), dtype=np.float32) * 10
+    lab = np.sort(rng.integers(0, nc, n))
+    x = (centres[lab] + rng.standard_normal((n, d)).astype(np.float32) * np.float32(spread)).astype(np.float32)
+    x[rng.choice(n, 60, replace=False)] = x[rng.choice(n, 60)]                 # some exact duplicates on top
+    idx = check(x, k)
+    n_fb, n_full = hipknn.last_fallback_count(), hipknn.last_full_scan_count()
+    hipknn.use_fp64_prefilter(False)
+    try:
+        idx_b = check(x, k)
+        assert hipknn.last_full_scan_count() == hipknn.last_fallback_count()
+    finally:
+        hipknn.use_fp64_prefilter(True)
+    assert np.array_equal(idx, idx_b)
+    if d == 64 and csize == 500:
+        assert n_fb > n // 2                      # the case this stage exists for
+    assert n_full <= n_fb // 10 + 5               # and nearly all of them are settled from the short lists
+
+
 def test_forced_fallback_agrees(hip, oracle_built):
     x = np.random.default_rng(4).random((1800, 32), dtype=np.float32)
     x[100:140] = x[5]
