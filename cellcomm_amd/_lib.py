@@ -65,6 +65,11 @@ SIGNATURES = {
     'cc_knn_use_fp16_collect': (c_int, [c_int]),
     'cc_knn_last_fallback_count': (c_int64, []),
     'cc_knn_use_fp64_prefilter': (c_int, [c_int]),
+    'cc_comm_unique_id': (c_int, [c_void_p]),
+    'cc_comm_init': (c_int, [c_int, c_int, c_void_p, POINTER(c_void_p)]),
+    'cc_comm_free': (c_int, [c_void_p]),
+    'cc_allgather_f32': (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    'cc_knn_l2_sharded': (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cc_knn_last_full_scan_count': (c_int64, []),
     'cc_duplicate_representatives': (c_int, [c_void_p, c_int64, c_void_p]),
     'cc_profile_enable': (c_int, [c_int]),

@@ -57,6 +57,29 @@ class HipBackend:
         return knn_graph_device(enc_all.data_ptr(), n_total, enc_all.shape[1], k, q_begin, n_q, include_self, out=out)
 
 
+def encode_and_knn_native(encoder, local_matrix, k, comm, n_total, include_self=False, backend=None):
+    """The same path with the exchange done by the library itself (`comm.NativeComm`: RCCL through the C ABI,
+    no torch.distributed in the data path).  `local_matrix` must be block `shard_bounds(n_total, comm.world_size,
+    comm.rank)` of the global matrix.  Returns the same dict as `encode_and_knn`."""
+    backend = backend or HipBackend()
+    lo, hi = shard_bounds(n_total, comm.world_size, comm.rank)
+    n_local = local_matrix.shape[0]
+    if n_local != hi - lo:
+        raise ValueError(f'rank {comm.rank} of {comm.world_size} must hold rows [{lo}, {hi}) of {n_total}, got {n_local} rows')
+    width = encoder.encoding_size
+    per = -(-n_total // comm.world_size)
+    enc_local = backend.alloc(per, width)
+    if n_local < per:
+        enc_local[n_local:].zero_()
+        backend.torch.cuda.synchronize()
+    backend.encode_into(encoder, local_matrix, enc_local)
+    gathered = backend.alloc(comm.world_size * per, width)
+    comm.all_gather(enc_local.data_ptr(), per * width, gathered.data_ptr())     # the one collective
+    enc_all = gathered[:n_total]
+    idx, dst = backend.knn(enc_all, n_total, lo, n_local, k, include_self)
+    return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=lo, n_total=n_total)
+
+
 def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, group=None):
     """Run the hot path on this rank's block of cells.
 

@@ -163,6 +163,22 @@ int cc_knn_use_fp64_prefilter(int on);
  * or more than 4096 candidates under it). */
 int64_t cc_knn_last_full_scan_count(void);
 
+/* ---- the sharded path's one exchange (nothing in the reference: it is single-process) ----
+ * One process per GPU.  RCCL (librccl.so.1) is bound at run time on the first cc_comm_* call, so
+ * single-GPU users never load it.  Rank 0 makes the 128-byte id, the host program hands it to every
+ * rank (file, env, MPI, torch.distributed store ...), every rank calls cc_comm_init after cc_init. */
+int cc_comm_unique_id(void *out_128_bytes);
+int cc_comm_init(int nranks, int rank, const void *unique_id_128_bytes, void **comm);
+int cc_comm_free(void *comm);
+/* recv[nranks x count] <- every rank's send[count]; device pointers; returns when the data is in place. */
+int cc_allgather_f32(void *comm, const float *dev_send, int64_t count, float *dev_recv);
+/* This rank holds rows [rank*per, min(n_total, (rank+1)*per)) of the encodings, per = ceil(n_total/nranks)
+ * (device pointer, row-major [n_local x d]).  All-gathers the blocks over RCCL and writes the k nearest
+ * neighbours (GLOBAL row ids, same order and ties as cc_knn_l2) of this rank's rows to host_idx / host_dist
+ * [n_local x k].  Collective: every rank of the communicator must call it. */
+int cc_knn_l2_sharded(void *comm, const float *dev_local_x, int64_t n_local, int64_t n_total, int d, int k,
+                      int include_self, int32_t *host_idx, float *host_dist);
+
 /* ---- duplicate coordinates: the `ds` field of an encits document
  *      (reference src/intercepts/db_recorder.py:113-117, O(N·U) there) ------------- */
 
