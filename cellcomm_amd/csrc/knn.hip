@@ -390,6 +390,31 @@ __device__ __forceinline__ void wavebuf_flush(WaveBuf &wb, u64 *__restrict__ buf
   wb.n = 0;
 }
 
+// Park the accumulator entries at or below T: per register one compare whose lane mask is the ballot
+// (registers nobody passes in cost a compare and a scalar branch); passing lanes take consecutive slots by
+// mbcnt.  ~1.3 of a tile's 1024 pairs pass, so this replaces a 64-lane prefix scan per tile.
+__device__ __forceinline__ void park_passes(const f32x16 &acc, float T, float key_scale, unsigned cbase, int r,
+                                            WaveBuf &wb, u64 *__restrict__ buf, int *__restrict__ cursor, int64_t q0,
+                                            int64_t n_q, int cap, int lane) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const bool pass = acc[e] <= T;
+    const unsigned long long mask = __ballot(pass);
+    if (mask) {   // wave-uniform
+      const int cnt = __builtin_popcountll(mask);
+      if (wb.n + cnt > COL_WB) wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
+      if (pass) {
+        const int pos = wb.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                              __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+        wb.key[pos] = ((u64)f32_to_ordered(acc[e] * key_scale) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
+        wb.qr[pos] = r;
+      }
+      wb.n += cnt;
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+}
+
 template <int NG>
 __device__ __forceinline__ void collect_step(const float4 (&a)[NG], const float4 (&bq)[NG], int64_t b, int64_t NB,
                                              int64_t self_blk, int self_e, unsigned tail_vm, float T, WaveBuf &wb,
@@ -413,44 +438,7 @@ __device__ __forceinline__ void collect_step(const float4 (&a)[NG], const float4
       acc[e] = kill ? __builtin_nanf("") : acc[e];
     }
   }
-  const int c_l = count_regs<0, 16>(acc, T);
-  if (!__any(c_l)) return;
-  const unsigned cbase = (unsigned)(b * 32) + 4 * h;
-  // inclusive prefix sum of the per-lane pass counts over the wave
-  int incl = c_l;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int up = __shfl_up(incl, o);
-    if (lane >= o) incl += up;
-  }
-  const int total = __builtin_amdgcn_readlane(incl, 63);
-  if (total > COL_WB) {
-    // pathological step (threshold admits > 128 of 1024 pairs): bypass the parking buffer
-    const int64_t ql = q0 + r;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      if (acc[e] <= T && ql < n_q) {
-        const int pos = atomicAdd(cursor + ql, 1);
-        if (pos < cap) buf[ql * cap + pos] = ((u64)f32_to_ordered(acc[e]) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
-      }
-    }
-    return;
-  }
-  if (wb.n + total > COL_WB) wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
-  int pos = wb.n + incl - c_l;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const bool pass = acc[e] <= T;
-    if (__ballot(pass)) {
-      if (pass) {
-        wb.key[pos] = ((u64)f32_to_ordered(acc[e]) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
-        wb.qr[pos] = r;
-        ++pos;
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  wb.n += total;
+  park_passes(acc, T, 1.0f, (unsigned)(b * 32) + 4 * h, r, wb, buf, cursor, q0, n_q, cap, lane);
 }
 
 // Workgroup = 4 waves = 128 queries x one candidate split.  Candidate panels are staged through
@@ -676,49 +664,17 @@ __device__ __forceinline__ void collect16_step(const h8 *__restrict__ sb, const 
       acc[e] = kill ? __builtin_nanf("") : acc[e];
     }
   }
-  const int c_l = count_regs<0, 16>(acc, Ts);
-  if (!__any(c_l)) return;
-  const unsigned cbase = (unsigned)(b * 32) + 4 * h;
-  int incl = c_l;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int up = __shfl_up(incl, o);
-    if (lane >= o) incl += up;
-  }
-  const int total = __builtin_amdgcn_readlane(incl, 63);
-  if (total > COL_WB) {
-    const int64_t ql = q0 + r;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      if (acc[e] <= Ts && ql < n_q) {
-        const int pos = atomicAdd(cursor + ql, 1);
-        if (pos < cap)
-          buf[ql * cap + pos] = ((u64)f32_to_ordered(acc[e] * inv_s2) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
-      }
-    }
-    return;
-  }
-  if (wb.n + total > COL_WB) wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
-  int pos = wb.n + incl - c_l;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) {
-    const bool pass = acc[e] <= Ts;
-    if (__ballot(pass)) {
-      if (pass) {
-        wb.key[pos] = ((u64)f32_to_ordered(acc[e] * inv_s2) << 32) | (u64)(cbase + (e & 3) + 8 * (e >> 2));
-        wb.qr[pos] = r;
-        ++pos;
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  wb.n += total;
+  park_passes(acc, Ts, inv_s2, (unsigned)(b * 32) + 4 * h, r, wb, buf, cursor, q0, n_q, cap, lane);
 }
-
-constexpr int C16_CB = 4;  // candidate blocks per LDS stage
-
+#ifndef CC_KNN_C16_MINW
+#define CC_KNN_C16_MINW 3
+#endif
+#ifndef CC_KNN_C16_CB
+#define CC_KNN_C16_CB 2
+#endif
+constexpr int C16_CB = CC_KNN_C16_CB;  // candidate blocks per LDS stage
 template <int ND>
-__global__ __launch_bounds__(256, 2) void knn_collect16_kernel(
+__global__ __launch_bounds__(256, CC_KNN_C16_MINW) void knn_collect16_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const float *__restrict__ x,
     const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
     const float *__restrict__ T, float s, int S, int64_t NBs, int cap, u64 *__restrict__ buf,
