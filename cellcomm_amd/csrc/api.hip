@@ -3,6 +3,8 @@
 #include <cmath>
 #include <mutex>
 
+#include <cstdlib>
+
 #include "common.h"
 
 namespace cc {
@@ -491,6 +493,9 @@ int cc_encoder_create(int arch, int G, int E, int dtype, void **enc) {
   CC_REQUIRE(G >= 1 && E >= 1, "gene_size=%d and encoding_size=%d must be >= 1", G, E);
   Encoder *e = new Encoder();
   e->arch = arch; e->G = G; e->E = E; e->dtype = dtype;
+  // rows per pass: 8192 rows are exactly 2 + 1 rounds of fp32 tiles (128 x 128, 3 per CU); the fp16 kernels
+  // (256 x 128 tiles, 2 per CU) fill whole rounds with twice that (C3 step 69 -> 65 ms, tools/batch_sweep.sh)
+  e->batch = dtype == CC_DTYPE_F32 ? 8192 : 16384;
   encoder_shapes(e);
   *enc = e;
   return CC_OK;

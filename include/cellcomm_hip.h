@@ -69,7 +69,7 @@ int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols);
  * BatchNormalization contributes gamma, beta, moving_mean, moving_variance).
  * reference src/bigan_cont.py:31-41, src/bigan_classify.py:29-40. */
 int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols);
-/* Rows processed per pass through the layer stack (default 8192). */
+/* Rows processed per pass through the layer stack (default 8192 for CC_DTYPE_F32, 16384 for the fp16 dtypes). */
 int cc_encoder_set_batch(void *enc, int64_t batch_rows);
 /* CC_DTYPE_F16X2 only: passes of the last cc_encode* call whose input was not exactly
  * representable in fp16 and therefore ran on the fp32 kernels instead. */
