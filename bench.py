@@ -196,8 +196,9 @@ def main():
     if rank == 0:
         traffic = None   # HBM-side bytes per launch from the PMC passes committed under profiles/
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))['kernels']['cc::gemm_bias_act_kernel<1>']
-            traffic = (2 * pmc['FETCH_SIZE_KB']['mean_per_launch'] + pmc['WRITE_SIZE_KB']['mean_per_launch']) * 1024
+            kernels = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))['kernels']
+            pmc = next(v for k, v in kernels.items() if 'gemm_bias_act_kernel<1>' in k)
+            traffic = (2 * pmc['FETCH_SIZE']['mean_per_launch'] + pmc['WRITE_SIZE']['mean_per_launch']) * 1024
         except Exception:
             pass
         g1 = prof['gemm_l1']
