@@ -29,6 +29,42 @@ def test_config2_encode_only_10k_x_20k_latent32(hip):
     assert np.array_equal(enc.predict(host.take(rows)), out[rows])      # row results are batch independent
 
 
+def test_config3_headline_size_properties(hip, oracle_built):
+    # configs[2], the bench workload at full size (100k cells x 30k genes, latent 64, k = 15): oracle on seeded
+    # samples plus properties that do not need it — idempotence, independence of a row's encoding from the rows
+    # around it, sortedness / self-exclusion / symmetry of the neighbour lists, f16x2 within tolerance of fp32.
+    n, g, e, k = 100000, 30000, 64, 15
+    m, (indptr, indices, values) = synth.synth_csr_device(n, g, seed=1234)
+    enc = cc.HipEncoder(e, g, 'cont', seed=4321)
+    out = enc.predict(m)
+    assert out.shape == (n, e) and np.all(np.isfinite(out)) and np.all(out > 0) and np.all(out < 1)
+    assert np.array_equal(enc.predict(m), out)                                    # idempotent, bit for bit
+    host = cc.CellMatrix(indptr.cpu().numpy(), indices.cpu().numpy(), values.cpu().numpy(), g)
+    rng = np.random.default_rng(3)
+    rows = rng.choice(n, 48, replace=False)
+    truth = eo.forward('cont', enc.get_weights(), host.take(rows).to_dense())
+    assert max_rel(out[rows], truth) <= 1e-4
+    block = host.take(np.arange(36990, 42010))                                    # straddles pass boundaries of the full run
+    assert np.array_equal(enc.predict(block), out[36990:42010])
+    enc2 = cc.HipEncoder(e, g, 'cont', seed=4321, dtype='f16x2')
+    out2 = enc2.predict(m)
+    assert enc2.fp32_fallback_passes() == 0
+    assert max_rel(out2[rows], truth) <= 1e-4 and max_rel(out2, out.astype(np.float64)) <= 2e-4
+    idx, dist = cc.knn_graph(out, k)
+    assert np.array_equal(cc.knn_graph(out, k)[0], idx)
+    assert np.all(idx != np.arange(n)[:, None]) and np.all(idx >= 0) and np.all(idx < n)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    for q in rng.choice(n, 48, replace=False):
+        wi, wd = ko.knn(out, k, q_begin=int(q), n_q=1)
+        assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0])
+    # symmetry: if j is i's nearest neighbour and i is listed by j, both report the same distance
+    j = idx[:, 0]
+    back = (idx[j] == np.arange(n)[:, None])
+    has = back.any(axis=1)
+    assert has.mean() > 0.3
+    assert np.array_equal(dist[j][back][:], dist[has, 0])
+
+
 def test_config4_shard_of_1m_candidates(hip, oracle_built):
     # configs[3]: 1M cells sharded over 8 GPUs — one rank's kNN: its 125k queries against all 1M
     # encodings, global indices; 48 seeded queries checked bit-exact against the oracle.
