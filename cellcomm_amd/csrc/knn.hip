@@ -41,6 +41,10 @@ using u64 = unsigned long long;
 
 static bool g_force_fallback = false;
 static bool g_force_route_a = false;  // test hook: always take the full-select route
+#ifndef CC_KNN_SELECT16
+#define CC_KNN_SELECT16 1
+#endif
+static bool g_use_fp16_select = CC_KNN_SELECT16 != 0;   // sample pass of stage 1b on the fp16 matrix cores too
 static bool g_use_fp16_collect = true; // stage 1b collect on the fp16 matrix cores when the data's scale allows
 static bool g_use_fp64_prefilter = true; // stage 3: float64 matrix-core prefilter in front of the exact scan
 static int64_t g_last_fallback = 0;
@@ -195,6 +199,10 @@ __device__ __forceinline__ int count_regs(const f32x16 &acc, float tau) {
   return c;
 }
 
+__device__ __forceinline__ void select_filter(f32x16 &acc, int64_t b, int64_t NB, int64_t self_blk, int self_e,
+                                              unsigned tail_vm, float &tau, u64 *list, float *tau_s, int *cnt,
+                                              int LS, int KP, int CAP, int lane);
+
 // One wave owns 32 queries (MFMA columns) and their LDS lists exclusively, so appends
 // need no atomics: lanes r and r+32 (the two row-halves of query r) split the slots
 // [cnt, cnt + c0 + c1) by exchanging their pass counts.  Lists hold CAP = K' + 16 keys
@@ -206,7 +214,6 @@ template <int NG>
 __device__ __forceinline__ void select_step(const float4 (&a)[NG], const float4 (&bq)[NG], int64_t b, int64_t NB,
                                             int64_t self_blk, int self_e, unsigned tail_vm, float &tau, u64 *list,
                                             float *tau_s, int *cnt, int LS, int KP, int CAP, int lane) {
-  const int r = lane & 31, h = lane >> 5;
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -217,6 +224,16 @@ __device__ __forceinline__ void select_step(const float4 (&a)[NG], const float4 
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].z, bq[g].z, acc, 0, 0, 0);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g].w, bq[g].w, acc, 0, 0, 0);
   }
+  select_filter(acc, b, NB, self_blk, self_e, tail_vm, tau, list, tau_s, cnt, LS, KP, CAP, lane);
+}
+
+// The list side of a select step: filter the 32 x 32 tile `acc` against the running thresholds and
+// append the survivors (shared by the fp32 and the fp16-split tiles; any monotone scaling of the
+// distances works as long as tau and the keys live in the same scale).
+__device__ __forceinline__ void select_filter(f32x16 &acc, int64_t b, int64_t NB, int64_t self_blk, int self_e,
+                                              unsigned tail_vm, float &tau, u64 *list, float *tau_s, int *cnt,
+                                              int LS, int KP, int CAP, int lane) {
+  const int r = lane & 31, h = lane >> 5;
   // inadmissible candidates (the query itself, rows beyond N) become NaN: NaN <= tau is false
   if (__any(b == self_blk) || b == NB - 1) {
 #pragma unroll
@@ -635,6 +652,126 @@ __global__ void knn_pack16_kernel(const float *__restrict__ x, const float *__re
   const int64_t b = (f >> 6) / NT;
   const int64_t cand = b * 32 + (lane & 31);
   P16[f] = panel16_unit(x, mu, norms, cand, cand < N, d, ND, t, lane >> 5, s, s * s * (1.0f / 256.0f), false);
+}
+
+// ---- sample select on the fp16 matrix cores --------------------------------------------------
+// Same lists, same filter as knn_select_kernel; the 32 x 32 tile comes from the fp16-split panels
+// (3·ND + 1 MFMAs of 32 cycles instead of 4·NG of 64), in the arithmetic knn_collect16 filters with:
+// the threshold T then is a distance the collect pass reproduces bit for bit, so the m sampled points
+// that define it are always collected.  Distances live scaled by s² (a power of two) in the lists and
+// are unscaled, exactly, when the keys are written out.
+template <int ND>
+__device__ __forceinline__ void select16_step(const h8 (&ah)[ND + 1], const h8 (&al)[ND], const h8 (&bqh)[ND + 1],
+                                              const h8 (&bql)[ND], int64_t b, int64_t NB, int64_t self_blk, int self_e,
+                                              unsigned tail_vm, float &tau, u64 *list, float *tau_s, int *cnt, int LS,
+                                              int KP, int CAP, int lane) {
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bqh[t], acc, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bql[t], acc, 0, 0, 0);
+#pragma unroll
+  for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bqh[t], acc, 0, 0, 0);
+  select_filter(acc, b, NB, self_blk, self_e, tail_vm, tau, list, tau_s, cnt, LS, KP, CAP, lane);
+}
+
+template <int ND>
+__global__ __launch_bounds__(64, 3) void knn_select16_kernel(
+    const h8 *__restrict__ P16, const float *__restrict__ norms, const float *__restrict__ x,
+    const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
+    float s, int KP, int CAP, int S, int64_t NBs, int bstride, u64 *__restrict__ out_keys,
+    int *__restrict__ out_cnt) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = 2 * ND + 1;
+  const int LS = CAP + 1;
+  u64 *list = reinterpret_cast<u64 *>(smem);
+  float *tau_s = reinterpret_cast<float *>(list + 32 * LS);
+  int *cnt = reinterpret_cast<int *>(tau_s + 32);
+
+  const int64_t tile = blockIdx.x / S;
+  const int split = blockIdx.x % S;
+  const int64_t b_lo = split * NBs;
+  const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
+  const int lane = threadIdx.x;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t ql = tile * 32 + r;
+  const bool qvalid = ql < n_q;
+  const int64_t q = q_begin + ql;
+  const float s2 = s * s, inv_s2 = 1.0f / s2;
+
+  h8 bqh[ND + 1], bql[ND];
+#pragma unroll
+  for (int t = 0; t <= ND; ++t) bqh[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
+#pragma unroll
+  for (int t = 0; t < ND; ++t) bql[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, ND + 1 + t, h, -2.0f * s, 0.f, true);
+  if (lane < 32) {
+    cnt[r] = 0;
+    tau_s[r] = qvalid ? INFINITY : -INFINITY;
+  }
+  __builtin_amdgcn_wave_barrier();
+  float tau = tau_s[r];
+
+  int64_t self_blk = -1;
+  int self_e = -1;
+  if (qvalid && !include_self) {
+    const int row = (int)(q & 31);
+    if (((row >> 2) & 1) == h) {
+      self_blk = q >> 5;
+      self_e = (row & 3) | ((row >> 3) << 2);
+    }
+  }
+  unsigned tail_vm = 0xffffu;
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
+
+  // two register sets of candidate operands, ping-pong: block b+1 loads while b computes
+  h8 ah0[ND + 1], al0[ND], ah1[ND + 1], al1[ND];
+  {
+    const h8 *pb = P16 + b_lo * (NT * 64) + lane;
+#pragma unroll
+    for (int t = 0; t <= ND; ++t) ah0[t] = pb[t * 64];
+#pragma unroll
+    for (int t = 0; t < ND; ++t) al0[t] = pb[(ND + 1 + t) * 64];
+  }
+  for (int64_t b = b_lo; b < b_hi; b += 2 * bstride) {
+    const int64_t b1 = b + bstride, b2 = b + 2 * bstride;
+    {
+      const h8 *pb = P16 + ((b1 < b_hi) ? b1 : b) * (NT * 64) + lane;
+#pragma unroll
+      for (int t = 0; t <= ND; ++t) ah1[t] = pb[t * 64];
+#pragma unroll
+      for (int t = 0; t < ND; ++t) al1[t] = pb[(ND + 1 + t) * 64];
+    }
+    select16_step<ND>(ah0, al0, bqh, bql, b, NB, self_blk, self_e, tail_vm, tau, list, tau_s, cnt, LS, KP, CAP, lane);
+    if (b1 < b_hi) {
+      {
+        const h8 *pb = P16 + ((b2 < b_hi) ? b2 : b1) * (NT * 64) + lane;
+#pragma unroll
+        for (int t = 0; t <= ND; ++t) ah0[t] = pb[t * 64];
+#pragma unroll
+        for (int t = 0; t < ND; ++t) al0[t] = pb[(ND + 1 + t) * 64];
+      }
+      select16_step<ND>(ah1, al1, bqh, bql, b1, NB, self_blk, self_e, tail_vm, tau, list, tau_s, cnt, LS, KP, CAP, lane);
+    }
+  }
+
+  for (int qi = 0; qi < 32; ++qi) {
+    compact_list(list + qi * LS, cnt + qi, tau_s + qi, KP, lane);
+    const int64_t qo = tile * 32 + qi;
+    if (qo < n_q) {
+      const int c = cnt[qi];
+      const int64_t slot = qo * S + split;
+      for (int i = lane; i < c; i += 64) {
+        const u64 e = list[qi * LS + i];
+        const float dist = ordered_to_f32((unsigned)(e >> 32)) * inv_s2;   // exact: s² is a power of two
+        out_keys[slot * KP + i] = ((u64)f32_to_ordered(dist) << 32) | (e & 0xffffffffull);
+      }
+      if (lane == 0) out_cnt[slot] = c;
+    }
+  }
 }
 
 template <int ND>
@@ -1176,6 +1313,25 @@ static int run_select(int NG, const SelectArgs &a, int KP, int CAP, int S, int64
   return CC_OK;
 }
 
+static int run_select16(int ND, const h8 *P16, const SelectArgs &a, float s, int KP, int CAP, int S, int64_t NBs,
+                        int bstride, u64 *keys, int *cnts) {
+  const int64_t nwaves = ceil_div(a.n_q, 32) * S;
+  const size_t lds = sizeof(u64) * 32 * (size_t)(CAP + 1) + 32 * 8;
+#define CC_SEL16(NDV)                                                                                          \
+  case NDV:                                                                                                    \
+    hipLaunchKernelGGL(knn_select16_kernel<NDV>, dim3((unsigned)nwaves), dim3(64), lds, stream(), P16, a.norms, \
+                       a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, s, KP, CAP, S, NBs, bstride, \
+                       keys, cnts);                                                                            \
+    break;
+  switch (ND) {
+    CC_SEL16(1) CC_SEL16(2) CC_SEL16(4) CC_SEL16(8)
+    default: CC_REQUIRE(false, "knn: no fp16 select kernel for ND=%d", ND);
+  }
+#undef CC_SEL16
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
 static int run_collect(int NG, const SelectArgs &a, const float *T, int S, int64_t NBs, int cap, u64 *buf,
                        int *cursor) {
   const int64_t nwg = ceil_div(a.n_q, 128) * S;
@@ -1353,23 +1509,8 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
         if (SS == 1) NBss = NB;
       }
       if ((rc = Tq.alloc(sizeof(float) * (size_t)n_q))) return rc;
-      if (collect_all) {
-        hipLaunchKernelGGL(knn_fill_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(), Tq.as<float>(),
-                           n_q, INFINITY);
-      } else {
-        if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS) * (size_t)SS))) return rc;
-        if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q * (size_t)SS))) return rc;
-        if ((rc = run_select(NG, sa, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) return rc;
-        hipLaunchKernelGGL(knn_threshold_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(),
-                           skeys.as<u64>(), scnts.as<int>(), n_q, SS, KPS, m, Tq.as<float>());
-      }
-      // 1b-ii: collect over all candidates, 8 splits (one per XCD) or fewer for short scans
-      make_splits(NB, 8, &S, &NBs);
-      if ((rc = cbuf.alloc(sizeof(u64) * (size_t)n_q * (size_t)col_cap))) return rc;
-      if ((rc = ccur.alloc(sizeof(int) * (size_t)n_q))) return rc;
-      CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
-      // collect on the fp16 matrix cores when the centred data's scale keeps s, s² and the scaled
-      // norms well inside the fp32/fp16 ranges; otherwise on the fp32 ones
+      // both passes of 1b run on the fp16 matrix cores when the centred data's scale keeps s, s² and the
+      // scaled norms well inside the fp32/fp16 ranges; otherwise on the fp32 ones
       int ND16 = 0;
       for (int o : {1, 2, 4, 8})
         if (16 * o >= d) { ND16 = o; break; }
@@ -1391,6 +1532,29 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
         if ((rc = P16.alloc(sizeof(h8) * (size_t)units))) return rc;
         hipLaunchKernelGGL(knn_pack16_kernel, dim3((unsigned)ceil_div(units, 256)), dim3(256), 0, stream(), d_x,
                            mu.as<float>(), norms.as<float>(), N, d, ND16, NB, scale16, P16.as<h8>());
+      }
+      if (collect_all) {
+        hipLaunchKernelGGL(knn_fill_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(), Tq.as<float>(),
+                           n_q, INFINITY);
+      } else {
+        if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS) * (size_t)SS))) return rc;
+        if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q * (size_t)SS))) return rc;
+        if (scale16 > 0.f && g_use_fp16_select && ND16 <= 4) {   // ND = 8 (d > 64) spills: fp32 select there
+          if ((rc = run_select16(ND16, P16.as<h8>(), sa, scale16, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(),
+                                 scnts.as<int>())))
+            return rc;
+        } else if ((rc = run_select(NG, sa, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) {
+          return rc;
+        }
+        hipLaunchKernelGGL(knn_threshold_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(),
+                           skeys.as<u64>(), scnts.as<int>(), n_q, SS, KPS, m, Tq.as<float>());
+      }
+      // 1b-ii: collect over all candidates, 8 splits (one per XCD) or fewer for short scans
+      make_splits(NB, 8, &S, &NBs);
+      if ((rc = cbuf.alloc(sizeof(u64) * (size_t)n_q * (size_t)col_cap))) return rc;
+      if ((rc = ccur.alloc(sizeof(int) * (size_t)n_q))) return rc;
+      CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
+      if (scale16 > 0.f) {
         if ((rc = run_collect16(ND16, P16.as<h8>(), sa, Tq.as<float>(), scale16, S, NBs, col_cap, cbuf.as<u64>(),
                                 ccur.as<int>())))
           return rc;
