@@ -132,10 +132,8 @@ def main():
     host_enc = host_enc_t.numpy()
 
     def step():
-        res = pipeline.encode_and_knn(enc, local, args.k, backend=backend)
-        q0 = res['q_begin']
-        host_enc_t.copy_(res['encodings'][q0:q0 + (hi - lo)])      # D2H into pinned memory
-        return res
+        # encodings reach pinned host memory on a side stream while the kNN search runs
+        return pipeline.encode_and_knn(enc, local, args.k, backend=backend, host_encodings=host_enc_t)
 
     def fence():
         torch.cuda.synchronize()

@@ -60,7 +60,7 @@ __device__ __forceinline__ float ordered_to_f32(unsigned o) {
 }
 
 // ---- centroid (fixed summation order: deterministic) ------------------------------
-constexpr int MEAN_BLOCKS = 256;
+constexpr int MEAN_BLOCKS = 2048;   // fixed partition: the centroid does not depend on the launch shape
 __global__ void knn_colsum_kernel(const float *__restrict__ x, int64_t N, int d, double *__restrict__ partial) {
   const int c = threadIdx.x;
   if (c >= d) return;
@@ -68,7 +68,15 @@ __global__ void knn_colsum_kernel(const float *__restrict__ x, int64_t N, int d,
   const int64_t lo = (int64_t)blockIdx.x * per;
   const int64_t hi = lo + per < N ? lo + per : N;
   double s = 0.0;
-  for (int64_t i = lo; i < hi; ++i) s += (double)x[i * d + c];
+  int64_t i = lo;
+  for (; i + 4 <= hi; i += 4) {   // four independent loads in flight, summed in row order
+    const float v0 = x[i * d + c], v1 = x[(i + 1) * d + c], v2 = x[(i + 2) * d + c], v3 = x[(i + 3) * d + c];
+    s += (double)v0;
+    s += (double)v1;
+    s += (double)v2;
+    s += (double)v3;
+  }
+  for (; i < hi; ++i) s += (double)x[i * d + c];
   partial[(int64_t)blockIdx.x * d + c] = s;
 }
 __global__ void knn_mean_kernel(const double *__restrict__ partial, int64_t N, int d, float *__restrict__ mu) {
@@ -86,18 +94,28 @@ __device__ __forceinline__ float centred(float x, float mu) { return __fsub_rn(x
 __global__ void knn_norm_kernel(const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d,
                                 float *__restrict__ norms, unsigned *__restrict__ maxnorm_bits) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
   double s = 0.0;
   float amax = 0.f;
-  for (int t = 0; t < d; ++t) {
-    const float y = centred(x[i * d + t], mu[t]);
-    amax = fmaxf(amax, fabsf(y));
-    s += (double)y * (double)y;
+  if (i < N) {
+    for (int t = 0; t < d; ++t) {
+      const float y = centred(x[i * d + t], mu[t]);
+      amax = fmaxf(amax, fabsf(y));
+      s += (double)y * (double)y;
+    }
+    norms[i] = (float)s;
   }
-  const float f = (float)s;
-  norms[i] = f;
-  atomicMax(maxnorm_bits, __float_as_uint(f));      // non-negative floats order as uints
-  atomicMax(maxnorm_bits + 1, __float_as_uint(amax));  // largest |centred coordinate| (scale of the fp16 panels)
+  // one pair of atomics per wave; non-negative floats order as uints (a NaN's bits win: the scale check rejects it)
+  unsigned fb = i < N ? __float_as_uint((float)s) : 0u, ab = i < N ? __float_as_uint(amax) : 0u;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned f2 = __shfl_xor(fb, o), a2 = __shfl_xor(ab, o);
+    fb = f2 > fb ? f2 : fb;
+    ab = a2 > ab ? a2 : ab;
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicMax(maxnorm_bits, fb);
+    atomicMax(maxnorm_bits + 1, ab);      // largest |centred coordinate| (scale of the fp16 panels)
+  }
 }
 
 // ---- candidate packing ---------------------------------------------------------
@@ -1444,7 +1462,6 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
   static DevBuf P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
       bnd_d, bnd_i, partial, mu;
   int rc;
-  if ((rc = P.alloc(sizeof(float4) * (size_t)(NB * NG * 64)))) return rc;
   if ((rc = norms.alloc(sizeof(float) * (size_t)N))) return rc;
   if ((rc = maxn.alloc(16))) return rc;
   if ((rc = partial.alloc(sizeof(double) * (size_t)MEAN_BLOCKS * (size_t)d))) return rc;
@@ -1471,11 +1488,20 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
                        mu.as<float>());
     hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, stream(), d_x,
                        mu.as<float>(), N, d, norms.as<float>(), maxn.as<unsigned>());
+    CC_HIP(hipGetLastError());
+  }
+  // the fp32 panels are packed only if an fp32 tile kernel runs (the fp16 route has its own panels)
+  SelectArgs sa{nullptr, norms.as<float>(), d_x, mu.as<float>(), N, d, NB, q_begin, n_q, include_self};
+  auto pack_fp32_panels = [&]() -> int {
+    if (sa.P) return CC_OK;
+    int prc;
+    if ((prc = P.alloc(sizeof(float4) * (size_t)(NB * NG * 64)))) return prc;
     hipLaunchKernelGGL(knn_pack_kernel, dim3((unsigned)ceil_div(NB * NG * 64, 256)), dim3(256), 0, stream(), d_x,
                        mu.as<float>(), norms.as<float>(), N, d, NG, NB, P.as<float4>());
     CC_HIP(hipGetLastError());
-  }
-  const SelectArgs sa{P.as<float4>(), norms.as<float>(), d_x, mu.as<float>(), N, d, NB, q_begin, n_q, include_self};
+    sa.P = P.as<float4>();
+    return CC_OK;
+  };
   // fp32 error bound of stage 1 relative to (‖q−μ‖² + ‖c−μ‖²), u = 2^-24:
   //   (2(d+2)+1)·u  d+2 fma terms on |terms| summing to <= 2(‖q‖²+‖c‖²), norms rounded to fp32
   // + 4(1+3u)·u     rounding of the centred coordinates fl(x−μ)
@@ -1543,8 +1569,9 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
           if ((rc = run_select16(ND16, P16.as<h8>(), sa, scale16, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(),
                                  scnts.as<int>())))
             return rc;
-        } else if ((rc = run_select(NG, sa, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) {
-          return rc;
+        } else {
+          if ((rc = pack_fp32_panels())) return rc;
+          if ((rc = run_select(NG, sa, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) return rc;
         }
         hipLaunchKernelGGL(knn_threshold_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(),
                            skeys.as<u64>(), scnts.as<int>(), n_q, SS, KPS, m, Tq.as<float>());
@@ -1563,8 +1590,9 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
         // + 12u  dropped lo·lo products and the 22-bit split of each coordinate
         // + 4u   rounding of the centred coordinates;  twice the sum is used.
         eps_coef = 2.0 * (3.0 * 16.0 * (3.0 * ND16 + 1.0) + 16.0) * 5.9604644775390625e-08;
-      } else if ((rc = run_collect(NG, sa, Tq.as<float>(), S, NBs, col_cap, cbuf.as<u64>(), ccur.as<int>()))) {
-        return rc;
+      } else {
+        if ((rc = pack_fp32_panels())) return rc;
+        if ((rc = run_collect(NG, sa, Tq.as<float>(), S, NBs, col_cap, cbuf.as<u64>(), ccur.as<int>()))) return rc;
       }
       S = 1;
       lcap = col_cap;
@@ -1583,6 +1611,7 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
       make_splits(NB, want > 8 ? 8 : want, &S, &NBs);
       if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KP) * (size_t)S))) return rc;
       if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q * (size_t)S))) return rc;
+      if ((rc = pack_fp32_panels())) return rc;
       if ((rc = run_select(NG, sa, KP, CAP, S, NBs, 1, skeys.as<u64>(), scnts.as<int>()))) return rc;
       hipLaunchKernelGGL(knn_merge_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256),
                          sizeof(u64) * 4 * (size_t)S * (size_t)KP, stream(), skeys.as<u64>(), scnts.as<int>(),

@@ -35,6 +35,7 @@ class HipBackend:
                 and torch.distributed.get_backend() == 'gloo':
             self.collective_device = 'cpu'
         self._out_key, self._out = None, None
+        self._side = None
         torch.cuda.set_device(_lib._INIT_DEVICE)
 
     def alloc(self, rows, width):
@@ -44,6 +45,16 @@ class HipBackend:
         n = matrix.shape[0]
         if n:
             encoder.predict_to_device(matrix, out.data_ptr(), 0, n)
+
+    def copy_out(self, dev_rows, host_pinned):
+        """Start the device-to-host copy of finished encodings on a side stream; returns the function that
+        waits for it.  (`encode_into` has returned, so the rows are complete.)"""
+        torch = self.torch
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        with torch.cuda.stream(self._side):
+            host_pinned.copy_(dev_rows, non_blocking=True)
+        return self._side.synchronize
 
     def knn(self, enc_all, n_total, q_begin, n_q, k, include_self):
         from .knn import knn_graph_device
@@ -80,7 +91,7 @@ def encode_and_knn_native(encoder, local_matrix, k, comm, n_total, include_self=
     return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=lo, n_total=n_total)
 
 
-def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, group=None):
+def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, group=None, host_encodings=None):
     """Run the hot path on this rank's block of cells.
 
     `local_matrix` holds the rows of this rank (block `shard_bounds(n_total, world,
@@ -89,6 +100,8 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
     idx=[n_local x k] int32 global neighbour ids, dist=[n_local x k] float32 (with
     HipBackend these are views of pinned buffers that the next call overwrites),
     q_begin=first global row of this rank, n_total=...).
+    `host_encodings` (optional, a pinned [n_local x E] float32 torch tensor, HipBackend only) receives this
+    rank's encodings; the device-to-host copy runs on a side stream underneath the kNN search.
     """
     backend = backend or HipBackend()
     torch = backend.torch
@@ -100,7 +113,10 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
     if not distributed:
         enc_all = backend.alloc(n_local, width)
         backend.encode_into(encoder, local_matrix, enc_all)
+        done = backend.copy_out(enc_all, host_encodings) if host_encodings is not None else None
         idx, dst = backend.knn(enc_all, n_local, 0, n_local, k, include_self)
+        if done is not None:
+            done()
         return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=0, n_total=n_local)
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
@@ -118,6 +134,7 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
     if n_local < per:
         enc_local[n_local:].zero_()
     backend.encode_into(encoder, local_matrix, enc_local)
+    done = backend.copy_out(enc_local[:n_local], host_encodings) if host_encodings is not None else None
     gathered = backend.alloc(world * per, width)
     if backend.device == 'cuda':
         torch.cuda.synchronize()                # encoder ran on the library's stream
@@ -132,4 +149,6 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
     else:
         enc_all = torch.cat([gathered[r * per:r * per + int(counts[r])] for r in range(world)]).contiguous()
     idx, dst = backend.knn(enc_all, n_total, q_begin, n_local, k, include_self)
+    if done is not None:
+        done()
     return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=q_begin, n_total=n_total)

@@ -53,6 +53,17 @@ def test_encode_and_knn_single_gpu(hip, oracle_built, arch):
     assert res['q_begin'] == 0 and res['n_total'] == n
 
 
+def test_host_copy_of_encodings_under_the_knn(hip, oracle_built):
+    import torch
+    n, g, e, k = 3000, 2000, 32, 15
+    m = synth.synth_csr(n, g, density=0.05, seed=21)
+    enc = cc.HipEncoder(e, g, 'cont', seed=2)
+    pinned = torch.empty((n, e), dtype=torch.float32, pin_memory=True)
+    res = pipeline.encode_and_knn(enc, m, k, host_encodings=pinned)
+    assert np.array_equal(pinned.numpy(), res['encodings'].cpu().numpy())
+    assert np.array_equal(pinned.numpy(), enc.predict(m))
+
+
 def test_device_resident_csr(hip, oracle_built):
     m_dev, (indptr, indices, values) = synth.synth_csr_device(700, 3000, seed=5)
     host = cc.CellMatrix(indptr.cpu().numpy(), indices.cpu().numpy(), values.cpu().numpy(), 3000)
