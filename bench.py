@@ -123,7 +123,7 @@ def main():
     _lib.ensure_init(local_rank)
 
     lo, hi = pipeline.shard_bounds(args.cells, world, rank)
-    # every rank draws the same global stream and keeps its block, so the union is the N=1 input
+    # each rank synthesises its own block of rows (same distribution, rank-specific seed); weights are identical
     local, _keep = synth.synth_csr_device(hi - lo, args.genes, density=0.05, seed=1234 + rank)
     enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321,
                         batch_rows=args.batch_rows or None, dtype=args.dtype)
