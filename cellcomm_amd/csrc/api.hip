@@ -441,7 +441,7 @@ using namespace cc;
 
 extern "C" {
 
-int cc_version(void) { return 100; }
+int cc_version(void) { return 101; }   // 101: cc_comm_*, cc_knn_l2_sharded, float64 prefilter hooks
 const char *cc_last_error(void) { return g_err.c_str(); }
 
 int cc_device_count(void) {
