@@ -46,10 +46,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #ifndef CC_GEMM_SETPRIO
 #define CC_GEMM_SETPRIO 1
 #endif
-// CC_GEMM_DBUF=1: two LDS stages and ONE barrier per K-step (experiment, see tools/gemm_sweep.sh)
-#ifndef CC_GEMM_DBUF
-#define CC_GEMM_DBUF 0
-#endif
 
 // CC_GEMM_PACE=1 (experiment, off): workgroups that share panels are kept within a few K-steps of each
 // other (chunks of CC_GEMM_PACE_EVERY K-steps, at most CC_GEMM_PACE_LEAD + 1 chunks ahead of the slowest
@@ -91,6 +87,98 @@ __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf
 __device__ unsigned long long g_gemm_trace[16384 * 4];
 #endif
 
+// State of the (optional) pacing experiment carried through the K loop.
+struct PaceState {
+  int *pace_grp = nullptr;
+  int pace_size = 0, pace_budget = 0, pace_seen = 0, wave_u = 0;
+};
+
+// The K loop of one wave (wave tile = MTV x NTV blocks of 32 x 32; only 2 x 2 is instantiated).
+// Tried and dropped: edge variants that skip the blocks outside the matrix (N = 3000 leaves the second wave
+// column of the last n-tile all padding, 1/48 of layer 1's MFMAs).  A second instantiation of this loop in
+// the kernel made the allocator spill (336 B scratch), and a staging-only path for all-padding waves,
+// which compiles cleanly, gains nothing: the workgroup still runs at the pace of its three full waves.
+template <int KCLASS, int MTV, int NTV>
+__device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA], f32x4 (&rb)[NB], const float *(&pa)[NA],
+                                            const f32x4 *&wt, const int (&a_lr)[NA], const float *__restrict__ A2,
+                                            int64_t m0, int64_t lda2, int KT1, int KT, float *As, f32x4 *Bs4,
+                                            const float *a_lds, const f32x4 *b_lds, int tid, int a_row, int a_k4,
+                                            PaceState &ps, int bid) {
+  for (int kt = 0; kt < KT; ++kt) {
+    const bool more = kt + 1 < KT;  // wave-uniform
+    if (more) {
+      if (kt + 1 == KT1) {  // first tile of segment 2: re-base the A pointers (once per kernel)
+        const float *base = A2 + m0 * lda2;
+#pragma unroll
+        for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * (int)lda2 + 4 * a_k4;
+      }
+#pragma unroll
+      for (int p = 0; p < NA; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
+#pragma unroll
+      for (int p = 0; p < NB; ++p) rb[p] = wt[p * GEMM_THREADS];
+      wt += TILE_W_FLOAT4;
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
+#if CC_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(1);
+#endif
+    if (MTV > 0 && NTV > 0) {
+#pragma unroll
+      for (int t = 0; t < BK / 8; ++t) {
+        f32x4 a[2], b[2];
+#pragma unroll
+        for (int mt = 0; mt < MTV; ++mt)
+          a[mt] = *reinterpret_cast<const f32x4 *>(a_lds + mt * 32 * LDS_A_STRIDE + 8 * t);
+#pragma unroll
+        for (int nt = 0; nt < NTV; ++nt) b[nt] = b_lds[2 * t * BN + nt * 32];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+          for (int mt = 0; mt < MTV; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NTV; ++nt)
+              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][u], b[nt][u], acc[mt][nt], 0, 0, 0);
+      }
+    }
+#if CC_GEMM_SETPRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    __syncthreads();
+    if (more) {
+      float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;
+#pragma unroll
+      for (int p = 0; p < NA; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
+#pragma unroll
+      for (int p = 0; p < NB; ++p) Bs4[tid + p * GEMM_THREADS] = rb[p];
+    }
+#if CC_GEMM_PACE
+    // wave 0 as a whole (wave-uniform control flow, scalar state: nothing per-lane stays live across
+    // the K loop): its 64 lanes' atomic adds are merged into one +64 by the compiler
+    if (ps.pace_grp && ps.wave_u == 0 && (kt + 1) % CC_GEMM_PACE_EVERY == 0) {
+      const int c = (kt + 1) / CC_GEMM_PACE_EVERY - 1;
+      // the counter this boundary depends on was read one boundary ago (ps.pace_seen: a whole chunk for the
+      // load to return), so a group that is in step never waits for memory here; nothing of this wave
+      // is in flight at this point, so consuming ps.pace_seen does not wait for the atomic below either
+      if (c >= CC_GEMM_PACE_LEAD && __builtin_amdgcn_readfirstlane(ps.pace_seen) < ps.pace_size) {
+        const int *w = ps.pace_grp + c - CC_GEMM_PACE_LEAD;
+        while (ps.pace_budget > 0 &&
+               __builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < ps.pace_size) {
+          __builtin_amdgcn_s_sleep(8);
+          --ps.pace_budget;
+        }
+      }
+      __hip_atomic_fetch_add(ps.pace_grp + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c + 1 >= CC_GEMM_PACE_LEAD)
+        ps.pace_seen = __hip_atomic_load(ps.pace_grp + c + 1 - CC_GEMM_PACE_LEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
+    __syncthreads();
+#ifdef CC_GEMM_TRACE
+    if (KCLASS == 1 && tid == 0 && bid < 16384 && kt == KT / 2) g_gemm_trace[4 * bid + 1] = wall_clock64();
+#endif
+  }
+}
+
 // KCLASS only names the instantiation (so profilers tell layer 1 / layer 2 / tail apart).
 template <int KCLASS>
 __global__
@@ -104,7 +192,7 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
                           const float *__restrict__ bias, int KT1, int KT, int N, int MT, int NT,
                           float *__restrict__ C, int64_t ldc, int act, int *__restrict__ pace, int pace_nch) {
   constexpr int STAGE_FLOATS = BM * LDS_A_STRIDE + TILE_W_FLOAT4 * 4;
-  __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS * (CC_GEMM_DBUF ? 2 : 1)];
+  __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
   float *As = lds;
   f32x4 *Bs4 = reinterpret_cast<f32x4 *>(lds + BM * LDS_A_STRIDE);
 
@@ -212,140 +300,17 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   const float *a_lds = As + (wm * 64 + r) * LDS_A_STRIDE + 4 * h;
   const f32x4 *b_lds = Bs4 + h * BN + wn * 64 + r;
 
-#if !CC_GEMM_DBUF
-  for (int kt = 0; kt < KT; ++kt) {
-    const bool more = kt + 1 < KT;  // wave-uniform
-    if (more) {
-      if (kt + 1 == KT1) {  // first tile of segment 2: re-base the A pointers (once per kernel)
-        const float *base = A2 + m0 * lda2;
-#pragma unroll
-        for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * (int)lda2 + 4 * a_k4;
-      }
-#pragma unroll
-      for (int p = 0; p < NA; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
-#pragma unroll
-      for (int p = 0; p < NB; ++p) rb[p] = wt[p * GEMM_THREADS];
-      wt += TILE_W_FLOAT4;
-    }
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
-#if CC_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-    for (int t = 0; t < BK / 8; ++t) {
-      f32x4 a[2], b[2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        a[mt] = *reinterpret_cast<const f32x4 *>(a_lds + mt * 32 * LDS_A_STRIDE + 8 * t);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) b[nt] = b_lds[2 * t * BN + nt * 32];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][u], b[nt][u], acc[mt][nt], 0, 0, 0);
-    }
-#if CC_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    __syncthreads();
-    if (more) {
-      float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;
-#pragma unroll
-      for (int p = 0; p < NA; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
-#pragma unroll
-      for (int p = 0; p < NB; ++p) Bs4[tid + p * GEMM_THREADS] = rb[p];
-    }
+  PaceState ps;
 #if CC_GEMM_PACE
-    // wave 0 as a whole (wave-uniform control flow, scalar state: nothing per-lane stays live across
-    // the K loop): its 64 lanes' atomic adds are merged into one +64 by the compiler
-    if (pace_grp && wave_u == 0 && (kt + 1) % CC_GEMM_PACE_EVERY == 0) {
-      const int c = (kt + 1) / CC_GEMM_PACE_EVERY - 1;
-      // the counter this boundary depends on was read one boundary ago (pace_seen: a whole chunk for the
-      // load to return), so a group that is in step never waits for memory here; nothing of this wave
-      // is in flight at this point, so consuming pace_seen does not wait for the atomic below either
-      if (c >= CC_GEMM_PACE_LEAD && __builtin_amdgcn_readfirstlane(pace_seen) < pace_size) {
-        const int *w = pace_grp + c - CC_GEMM_PACE_LEAD;
-        while (pace_budget > 0 &&
-               __builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < pace_size) {
-          __builtin_amdgcn_s_sleep(8);
-          --pace_budget;
-        }
-      }
-      __hip_atomic_fetch_add(pace_grp + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (c + 1 >= CC_GEMM_PACE_LEAD)
-        pace_seen = __hip_atomic_load(pace_grp + c + 1 - CC_GEMM_PACE_LEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  ps.pace_grp = pace_grp; ps.pace_size = pace_size; ps.pace_budget = pace_budget; ps.wave_u = wave_u;
 #endif
-    __syncthreads();
-#ifdef CC_GEMM_TRACE
-    if (KCLASS == 1 && tid == 0 && bid < 16384 && kt == KT / 2) g_gemm_trace[4 * bid + 1] = wall_clock64();
-#endif
-  }
+#define CC_KLOOP(MV, NV) gemm_k_loop<KCLASS, MV, NV>(acc, ra, rb, pa, wt, a_lr, A2, m0, lda2, KT1, KT, As, Bs4, a_lds, b_lds, tid, a_row, a_k4, ps, bid)
+  CC_KLOOP(2, 2);
+#undef CC_KLOOP
 #ifdef CC_GEMM_TRACE
   if (KCLASS == 1 && tid == 0 && bid < 16384) g_gemm_trace[4 * bid + 2] = wall_clock64();
 #endif
 
-#else
-  int cur = 0;
-  for (int kt = 0; kt < KT; ++kt) {
-    const bool more = kt + 1 < KT;  // wave-uniform
-    if (more) {
-      if (kt + 1 == KT1) {
-        const float *base = A2 + m0 * lda2;
-#pragma unroll
-        for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * (int)lda2 + 4 * a_k4;
-      }
-#pragma unroll
-      for (int p = 0; p < NA; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
-#pragma unroll
-      for (int p = 0; p < NB; ++p) rb[p] = wt[p * GEMM_THREADS];
-      wt += TILE_W_FLOAT4;
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    const float *a_cur = a_lds + cur * STAGE_FLOATS;
-    const f32x4 *b_cur = b_lds + cur * (STAGE_FLOATS / 4);
-#if CC_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
-#endif
-#pragma unroll
-    for (int t = 0; t < BK / 8; ++t) {
-      if (t == BK / 8 - 1) {
-        // the next tile goes into the other stage (last read one K-step ago, every wave is past that
-        // barrier) while the last quarter of this K-step's MFMAs is still to be issued
-#if CC_GEMM_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        if (more) {
-          float *aw = As + (cur ^ 1) * STAGE_FLOATS + a_row * LDS_A_STRIDE + 4 * a_k4;
-          f32x4 *bw = Bs4 + (cur ^ 1) * (STAGE_FLOATS / 4);
-#pragma unroll
-          for (int p = 0; p < NA; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
-#pragma unroll
-          for (int p = 0; p < NB; ++p) bw[tid + p * GEMM_THREADS] = rb[p];
-        }
-      }
-      f32x4 a[2], b[2];
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-        a[mt] = *reinterpret_cast<const f32x4 *>(a_cur + mt * 32 * LDS_A_STRIDE + 8 * t);
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) b[nt] = b_cur[2 * t * BN + nt * 32];
-#pragma unroll
-      for (int u = 0; u < 4; ++u)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][u], b[nt][u], acc[mt][nt], 0, 0, 0);
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-
-#endif
   // ---- epilogue: bias + activation, 128-byte row segments per half-wave ------
 #pragma unroll
   for (int nt = 0; nt < 2; ++nt) {
@@ -446,7 +411,7 @@ int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, in
   // pacing counters: [8 XCDs][groups of 32 workgroups][chunks of K-steps], zeroed per launch
   int *pace = nullptr;
   int pace_nch = 0;
-#if CC_GEMM_PACE && !CC_GEMM_DBUF
+#if CC_GEMM_PACE
   static int *pace_buf = nullptr;
   static size_t pace_cap = 0;
   if (g_gemm_pace && prof_class != CC_PROF_GEMM_TAIL && nwg >= 512) {
