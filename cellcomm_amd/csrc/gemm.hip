@@ -266,8 +266,9 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   // matters too: with `tid` and one more per-lane value alive across the K loop the
   // allocator moved the accumulators from v[0:15].. to v[2:17].. (and the A/B operands
   // with them) and the same instruction stream ran 11 % slower (137 -> 123 TFLOP/s), so
-  // the accumulators are pinned below.  (The fp16 and kNN kernels did not react to the
-  // same pin: tools/pin_sweep.sh.)
+  // the accumulators are pinned below (any 16-aligned VGPR placement measured the same; AGPRs were
+  // slower: the 84/84 register split spills).  The fp16 and kNN kernels did not react to the same pin
+  // (tools/pin_sweep.sh).
   f32x4 ra[NA], rb[NB];
 
   f32x16 acc[2][2];
