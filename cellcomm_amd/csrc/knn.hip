@@ -1515,7 +1515,7 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
     if (sampled) {
       // 1b-i: threshold from the sample (select with m-entry lists over every 8th block)
 #ifndef CC_KNN_SAMPLE_SPARE
-#define CC_KNN_SAMPLE_SPARE 48
+#define CC_KNN_SAMPLE_SPARE 32
 #endif
       const int KPS = (int)round_up(m, 16), CAPS = KPS + CC_KNN_SAMPLE_SPARE;
       // the sample pass is split over candidate ranges too, so that its (long-lived, list-carrying)
