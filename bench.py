@@ -28,6 +28,14 @@ PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense
 PEAK_HBM_GBS = 8000.0
 
 
+def baseline_metric():
+    """BASELINE.json's metric string, verbatim (the file travels with the repo)."""
+    try:
+        return json.load(open(os.path.join(ROOT, 'BASELINE.json')))['metric']
+    except Exception:
+        return 'cells/sec encode+kNN, 100k cells × 30k genes, 1/2/4/8 MI355X'
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -207,7 +215,7 @@ def main():
                       'rate': (v['work'] / (v['ms'] * 1e-3)) if v['ms'] > 0 else 0.0}
                   for k, v in prof.items() if v['launches']}
         line = {
-            'metric': 'cells/sec encode+kNN, 100k cells x 30k genes', 'value': args.cells * args.steps / elapsed,
+            'metric': baseline_metric(), 'value': args.cells * args.steps / elapsed,
             'unit': 'cells/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
