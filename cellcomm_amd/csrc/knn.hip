@@ -31,6 +31,8 @@
 //     error of stage 1: every point outside the list is then provably farther.
 //  3. fallback — uncertified queries (dense duplicates / near ties) are rescanned
 //     against all candidates in float64, bounded by their stage-2 k-th key.
+#include <cstdlib>
+
 #include "common.h"
 
 namespace cc {
@@ -1577,7 +1579,25 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
                            skeys.as<u64>(), scnts.as<int>(), n_q, SS, KPS, m, Tq.as<float>());
       }
       // 1b-ii: collect over all candidates, 8 splits (one per XCD) or fewer for short scans
-      make_splits(NB, 8, &S, &NBs);
+      // 8 splits = one per XCD (its slice of the panels stays in that XCD's L2).  Workgroups all take the same
+      // time, so what counts is whole rounds over the 768 resident slots (3 per CU): when 8 splits spill a few
+      // workgroups into an extra round (a 12.5k-query shard: 784), fewer, longer splits that fit the rounds win
+      // even though they lose the XCD affinity (measured: CC_KNN_COLLECT_SPLITS override, tools/knn_sweep.sh).
+      {
+        int want = 8;
+        static const int forced = std::getenv("CC_KNN_COLLECT_SPLITS") ? atoi(std::getenv("CC_KNN_COLLECT_SPLITS")) : 0;
+        if (forced > 0) {
+          want = forced;
+        } else {
+          const int64_t wgs = ceil_div(n_q, 128), slots = 768;
+          double best = 1e300;
+          for (int cand = 8; cand >= 5; --cand) {
+            const double cost = (double)ceil_div(wgs * cand, slots) * (double)ceil_div(NB, cand) * (cand == 8 ? 1.0 : 1.15);
+            if (cost < best) { best = cost; want = cand; }
+          }
+        }
+        make_splits(NB, want, &S, &NBs);
+      }
       if ((rc = cbuf.alloc(sizeof(u64) * (size_t)n_q * (size_t)col_cap))) return rc;
       if ((rc = ccur.alloc(sizeof(int) * (size_t)n_q))) return rc;
       CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
