@@ -52,8 +52,8 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra f16x2 measurement reported under "alt"')
     ap.add_argument('--no-profile', action='store_true', help='diagnostic: no HIP events in the timed region')
-    ap.add_argument('--cpu-sample-cells', type=int, default=2048)
-    ap.add_argument('--cpu-sample-knn', type=int, default=20000)
+    ap.add_argument('--cpu-sample-cells', type=int, default=8192)
+    ap.add_argument('--cpu-sample-knn', type=int, default=40000)
     return ap.parse_args()
 
 
