@@ -120,7 +120,7 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA]
     }
     __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
 #if CC_GEMM_SETPRIO
-    __builtin_amdgcn_s_setprio(1);
+    __builtin_amdgcn_s_setprio(CC_GEMM_SETPRIO);
 #endif
     if (MTV > 0 && NTV > 0) {
 #pragma unroll
