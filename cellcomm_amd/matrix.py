@@ -211,3 +211,32 @@ def load_cells(cells_file, verbose=False):
     if verbose:
         print(f'============ DONE! barcodes: {m.shape[0]}, genes: {m.shape[1]}')
     return m
+
+
+def store_cells(matrix, cell_file, block_rows=256):
+    """Write a CellMatrix as the dense CSV `DataFrame.to_csv` produces for the pivot of load_matrix
+    (index column `barcode`, one column per gene, shortest round-trip decimals), streamed in row blocks
+    so the dense table never exists in memory.  `load_cells` reads it back."""
+    cols = np.asarray(matrix.columns if matrix.columns is not None else np.arange(matrix.shape[1])).tolist()
+    idx = np.asarray(matrix.index if matrix.index is not None else np.arange(matrix.shape[0])).tolist()
+    with open(cell_file, 'w', newline='') as f:
+        f.write('barcode,' + ','.join(str(c) for c in cols) + '\n')
+        for lo in range(0, matrix.shape[0], block_rows):
+            hi = min(lo + block_rows, matrix.shape[0])
+            # values are held as float32: their shortest round-trip decimals are what pandas prints for the
+            # float64 originals whenever those had <= 7 significant digits (counts and their means do)
+            text = matrix.take(np.arange(lo, hi)).to_dense().astype(np.float32).astype(str)
+            for r in range(hi - lo):
+                f.write(str(idx[lo + r]))
+                f.write(',')
+                f.write(','.join(text[r].tolist()))
+                f.write('\n')
+
+
+def store_converted_cell_file(matrix_file, cell_file):
+    """The reference's `convert` step (reference src/__main__.py:76-81): .mtx triplets -> dense cell CSV."""
+    print('converting matrix file:')
+    m = load_matrix(matrix_file, verbose=True)
+    print('storing cell file:', cell_file, '... ', end='', flush=True)
+    store_cells(m, cell_file)
+    print('done')

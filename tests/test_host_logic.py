@@ -121,6 +121,29 @@ def test_load_cells_roundtrip(tmp_path):
     assert np.array_equal(back.to_dense(), m.to_dense())
 
 
+def test_store_converted_cell_file_writes_what_pandas_writes(tmp_path, capsys):
+    # the reference's `convert` step: DataFrame.to_csv of the pivot (reference src/__main__.py:76-81)
+    import pandas as pd
+    mtx = MTX
+    out = tmp_path / 'cells.csv'
+    matrix.store_converted_cell_file(mtx, out)
+    assert 'storing cell file:' in capsys.readouterr().out
+    df = pd.read_csv(mtx, header=None, skiprows=3, sep=r'\s+', names=['gene', 'barcode', 'p'])
+    want = df.pivot_table(index='barcode', columns='gene', values='p', fill_value=0).to_csv()
+    assert out.read_text() == want
+    back = matrix.load_cells(out)
+    m = matrix.load_matrix(mtx)
+    assert np.array_equal(back.to_dense(), m.to_dense())
+    assert list(back.index) == list(m.index) and [int(c) for c in back.columns] == list(m.columns)
+    # non-integer means (duplicate entries) keep their float64 repr
+    ragged = tmp_path / 'dup.mtx'
+    ragged.write_text('%%x\n%\n3 3 4\n1 1 1\n1 1 2\n3 2 7\n2 2 0.1\n')
+    out2 = tmp_path / 'dup.csv'
+    matrix.store_cells(matrix.load_matrix(ragged), out2)
+    df2 = pd.read_csv(ragged, header=None, skiprows=3, sep=r'\s+', names=['gene', 'barcode', 'p'])
+    assert out2.read_text() == df2.pivot_table(index='barcode', columns='gene', values='p', fill_value=0).to_csv()
+
+
 def test_synth_csr_properties():
     m = synth.synth_csr(64, 200, density=0.05, seed=3)
     assert m.shape == (64, 200)
