@@ -11,6 +11,7 @@ import pickle
 from collections import defaultdict
 
 import numpy as np
+import pandas as pd
 
 
 def cell_id_from(ix):
@@ -124,3 +125,74 @@ def read_enc_file(path):
 def load_barcodes(barcode_file):
     with open(barcode_file) as f:
         return [line.strip() for line in f.readlines()]
+
+
+def load_genes(genes_file):
+    """[(ensembl id, symbol), ...] of a 10x genes.tsv (reference src/intercepts/import_barcodes.py:78)."""
+    with open(genes_file) as f:
+        return [tuple(line.strip().split('\t')[:2]) for line in f.readlines()]
+
+
+def cells_and_genes_documents(source_id, matrix_file, barcodes_file, genes_file):
+    """The `cells` and `genes` collections the reference builds next to the encodings (reference
+    src/intercepts/import_barcodes.py:14-45,74-81), without Mongo and without its per-triplet Python loop:
+
+    * one cell document `{sid, cid, n, g: [{e, m, v}, ...]}` per RUN of consecutive triplets with the same
+      barcode column (the reference compares the column text with the previous line's), `g` sorted by value,
+      descending, ties in file order;
+    * one gene document `{sid, e, m, cids}` per ensembl id, in order of first appearance, `cids` in file order.
+
+    Returns (cells, genes).  The triplets are read once with pandas and grouped with NumPy; only the documents
+    themselves are Python objects."""
+    trip = pd.read_csv(matrix_file, header=None, skiprows=3, sep=' ', names=['gene', 'barcode', 'p'],
+                       dtype={'gene': np.int64, 'barcode': str}, skipinitialspace=False)
+    barcodes = load_barcodes(barcodes_file)
+    genes_src = load_genes(genes_file)
+    gene = trip['gene'].to_numpy()
+    bc_text = trip['barcode'].to_numpy()
+    cid = bc_text.astype(np.int64)
+    val = trip['p'].to_numpy().astype(np.int64)                  # int(p_val)
+    n = len(gene)
+    if n == 0:
+        return [], []
+    new_run = np.ones(n, dtype=bool)
+    new_run[1:] = bc_text[1:] != bc_text[:-1]
+    run = np.cumsum(new_run) - 1
+    # within a run: by value descending, stable
+    order = np.lexsort((np.arange(n), -val, run))
+    starts = np.flatnonzero(new_run)
+    ends = np.append(starts[1:], n)
+    e_of = [g[0] for g in genes_src]
+    m_of = [g[1] for g in genes_src]
+    g_sorted = gene[order] - 1
+    v_sorted = val[order].tolist()
+    cells = []
+    for s, t in zip(starts.tolist(), ends.tolist()):
+        c = int(cid[s])
+        cells.append({'sid': source_id, 'cid': c, 'n': barcodes[c - 1],
+                      'g': [{'e': e_of[g], 'm': m_of[g], 'v': v} for g, v in zip(g_sorted[s:t].tolist(), v_sorted[s:t])]})
+    # genes: ensembl ids in order of first appearance; the reference keys by ensembl id, so two gene lines that
+    # share one collapse into the first's document
+    ens_code = {}
+    codes = np.empty(len(genes_src), dtype=np.int64)
+    for i, e in enumerate(e_of):
+        codes[i] = ens_code.setdefault(e, len(ens_code))
+    tcode = codes[gene - 1]
+    first = np.full(len(ens_code), n, dtype=np.int64)
+    np.minimum.at(first, tcode, np.arange(n))
+    by_gene = np.argsort(tcode, kind='stable')
+    counts = np.bincount(tcode, minlength=len(ens_code))
+    offs = np.concatenate([[0], np.cumsum(counts)])
+    cid_by_gene = cid[by_gene].tolist()
+    first_line_of_code = {}
+    for i, e in enumerate(e_of):
+        first_line_of_code.setdefault(ens_code[e], i)
+    genes = []
+    for code in np.argsort(first, kind='stable').tolist():
+        if counts[code] == 0:
+            continue
+        i = first_line_of_code[code]
+        # `m` is the symbol of the gene line of the id's FIRST triplet (setdefault keeps the first document)
+        line = int(gene[first[code]] - 1)
+        genes.append({'sid': source_id, 'e': e_of[i], 'm': m_of[line], 'cids': cid_by_gene[offs[code]:offs[code + 1]]})
+    return cells, genes

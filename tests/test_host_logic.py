@@ -144,6 +144,35 @@ def test_store_converted_cell_file_writes_what_pandas_writes(tmp_path, capsys):
     assert out2.read_text() == df2.pivot_table(index='barcode', columns='gene', values='p', fill_value=0).to_csv()
 
 
+def test_cells_and_genes_documents(tmp_path):
+    # reference known answers (test/db_recorder_test.py:60-106) for its example files, then product == oracle
+    # on files that exercise what the loop form does with repeated barcode runs, ties and shared ensembl ids
+    src = 'example_barcodes.tsv'
+    files = (MTX, os.path.join(GOLDEN, 'example_barcodes.tsv'), os.path.join(GOLDEN, 'example_genes.tsv'))
+    for impl in (so.cells_and_genes_documents, schema.cells_and_genes_documents):
+        cells, genes = impl(src, *files)
+        assert len(cells) == 5 and len(genes) == 5
+        assert cells[0] == {'sid': src, 'cid': 1, 'n': 'AAACCTGGTGTCCTCT-1', 'g': [
+            {'e': 'ENSMUSG00000025902', 'm': 'Sox17', 'v': 11}, {'e': 'ENSMUSG00000102343', 'm': 'Gm37381', 'v': 6},
+            {'e': 'ENSMUSG00000089699', 'm': 'Gm1992', 'v': 1}, {'e': 'ENSMUSG00000109048', 'm': 'Rp1', 'v': 1}]}
+        assert cells[4] == {'sid': src, 'cid': 5, 'n': 'AAAGATGGTGATAAAC-1', 'g': [{'e': 'ENSMUSG00000109048', 'm': 'Rp1', 'v': 2}]}
+        assert genes[0] == {'sid': src, 'e': 'ENSMUSG00000089699', 'm': 'Gm1992', 'cids': [1, 2, 3]}
+        assert genes[4] == {'sid': src, 'e': 'ENSMUSG00000051951', 'm': 'Xkr4', 'cids': [2, 3, 4]}
+    rng = np.random.default_rng(4)
+    for case in range(6):
+        nb, ng, nt = int(rng.integers(1, 30)), int(rng.integers(1, 25)), int(rng.integers(0, 300))
+        bfile, gfile, mfile = tmp_path / f'b{case}.tsv', tmp_path / f'g{case}.tsv', tmp_path / f'm{case}.mtx'
+        bfile.write_text(''.join(f'BC{i}-1\n' for i in range(nb)))
+        ens = [f'ENS{int(rng.integers(0, max(1, ng - 2))):05d}' for _ in range(ng)]      # some ids shared by gene lines
+        gfile.write_text(''.join(f'{e}\tSym{i}\n' for i, e in enumerate(ens)))
+        bcs = rng.integers(1, nb + 1, nt)
+        if case % 2 == 0:
+            bcs = np.sort(bcs)                                                            # the usual 10x order
+        lines = [f'{int(rng.integers(1, ng + 1))} {int(b)} {int(rng.integers(1, 6))}' for b in bcs]
+        mfile.write_text('%%MatrixMarket\n%\n1 1 1\n' + ''.join(l + '\n' for l in lines))
+        assert schema.cells_and_genes_documents('s', mfile, bfile, gfile) == so.cells_and_genes_documents('s', mfile, bfile, gfile)
+
+
 def test_synth_csr_properties():
     m = synth.synth_csr(64, 200, density=0.05, seed=3)
     assert m.shape == (64, 200)
