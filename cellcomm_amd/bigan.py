@@ -98,6 +98,20 @@ class BasicBiGan:
         return changed
 
 
+    def print_params_changes(self, msg):
+        # reference src/bigan_basic.py:66-70, same line format
+        changed = self.params_changed()
+        print(msg, 'G|E|D changed:', f'{changed[0]:1} | {changed[1]:1} | {changed[2]:1},')
+
+
+def components_changed(p_now, p_orig):
+    """True when any array of two weight snapshots differs (reference src/bigan_basic.py:84-89)."""
+    for n, o in zip(p_now, p_orig):
+        if not np.array_equal(n, o):
+            return True
+    return False
+
+
 class ClassifyCellBiGan(BasicBiGan):
     """Softmax-encoder variant (reference src/bigan_classify.py:80-124)."""
 

@@ -259,6 +259,21 @@ def test_encoding_prediction_is_pure_delegation(known):
     enc.predict.assert_called_with(ka['genes'])
 
 
+def test_params_change_probe(capsys):
+    class Layer:
+        def __init__(self, ws): self.ws = ws
+        def get_weights(self): return self.ws
+    comps = [MagicMock(layers=[Layer([np.ones((2, 2)), np.zeros(2)]), Layer([np.ones(3)])]) for _ in range(3)]
+    gan = bigan.BasicBiGan(4, 9, lambda e, g: comps[0], lambda e, g: comps[1], lambda e, g: comps[2])
+    gan.print_params_changes('it 1')
+    assert capsys.readouterr().out == 'it 1 G|E|D changed: 0 | 0 | 0,\n'
+    comps[1].layers[0].ws[1][0] = 5.0
+    gan.print_params_changes('it 2')
+    assert capsys.readouterr().out == 'it 2 G|E|D changed: 0 | 1 | 0,\n'
+    assert bigan.components_changed([np.ones(2)], [np.ones(2)]) is False
+    assert bigan.components_changed([np.ones(2), np.zeros(1)], [np.ones(2), np.ones(1)]) is True
+
+
 def test_random_uniform_vector_shape():
     b, *_ = _mock_bigan()
     hv = b.random_uniform_vector(7)
