@@ -23,8 +23,8 @@
 //           and a whole 16 KiB tile is contiguous in HBM.
 // Lane (r = lane&31, h = lane>>5) of MFMA step (t,u) supplies k = 8t + 4h + u.
 // Global → register prefetch of K-step t+1 is issued before the MFMAs of step
-// t and written to LDS after them (2 barriers per K-step; 2–3 workgroups per
-// CU cover each other's barrier gaps).
+// t and written to LDS after them (2 barriers per K-step; 3 workgroups per CU
+// cover each other's barrier gaps — the CU's arbiter serves its oldest one first).
 //
 // Workgroup → tile map: XCD-aware (blockIdx%8 = XCD under round-robin dispatch
 // gets a contiguous slab of tiles) with grouped ordering (8 M-tiles share each
@@ -39,7 +39,7 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // Tuned on MI355X (tools/gemm_sweep.sh): 3 workgroups per CU (<=168 VGPRs) and a raised
-// priority over the MFMA cluster gave 127 -> 136 TFLOP/s on layer 1.
+// priority over the MFMA cluster gave 127 -> 137 TFLOP/s on layer 1 (139 with the K loop as it is now).
 #ifndef CC_GEMM_MINWAVES
 #define CC_GEMM_MINWAVES 3
 #endif
