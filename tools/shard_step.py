@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""What one rank of a P-GPU run does per step, measured on one GPU: encode its 100k/P cells, then search
+its queries against 100k candidates (the other ranks' encodings are stand-ins already in HBM).  Everything
+but the all-gather itself, so N=1 time / this time is the scaling the collective can only lower."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import cellcomm_amd as cc
+from cellcomm_amd import _lib, synth
+from cellcomm_amd.knn import knn_graph_device
+
+_lib.ensure_init(0)
+N, G, E, K = 100000, 30000, 64, 15
+enc = cc.HipEncoder(E, G, 'cont', seed=4321)
+full = torch.sigmoid(torch.randn((N, E), device='cuda'))
+base = None
+for P in (1, 2, 4, 8):
+    n = -(-N // P)
+    m, _ = synth.synth_csr_device(n, G, seed=1234)
+    pinned_enc = torch.empty((n, E), pin_memory=True)
+    idx = np.empty((n, K), np.int32); dist = np.empty((n, K), np.float32)
+    def step():
+        enc.predict_to_device(m, full.data_ptr(), 0, n)          # this rank's block = rows [0, n)
+        pinned_enc.copy_(full[:n], non_blocking=True)
+        knn_graph_device(full.data_ptr(), N, E, K, 0, n, out=(idx, dist))
+        torch.cuda.synchronize()
+    step()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    ms = (time.perf_counter() - t0) / 5 * 1e3
+    base = base or ms
+    print(f'P={P}: {n} cells per rank, {ms:.2f} ms per step -> {N / ms * 1e3:,.0f} cells/s if the all-gather were free, x{base / ms:.2f}', flush=True)
+    del m
