@@ -141,7 +141,8 @@ def main():
 
     def step():
         # encodings reach pinned host memory on a side stream while the kNN search runs
-        return pipeline.encode_and_knn(enc, local, args.k, backend=backend, host_encodings=host_enc_t)
+        return pipeline.encode_and_knn(enc, local, args.k, backend=backend, host_encodings=host_enc_t,
+                                       n_total=args.cells if world > 1 else None)
 
     def fence():
         torch.cuda.synchronize()

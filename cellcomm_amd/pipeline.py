@@ -91,7 +91,8 @@ def encode_and_knn_native(encoder, local_matrix, k, comm, n_total, include_self=
     return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=lo, n_total=n_total)
 
 
-def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, group=None, host_encodings=None):
+def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, group=None, host_encodings=None,
+                   n_total=None):
     """Run the hot path on this rank's block of cells.
 
     `local_matrix` holds the rows of this rank (block `shard_bounds(n_total, world,
@@ -102,6 +103,8 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
     q_begin=first global row of this rank, n_total=...).
     `host_encodings` (optional, a pinned [n_local x E] float32 torch tensor, HipBackend only) receives this
     rank's encodings; the device-to-host copy runs on a side stream underneath the kNN search.
+    `n_total` (optional): total number of cells when every rank holds block `shard_bounds(n_total, world, rank)`;
+    saves the small collective that otherwise exchanges the block sizes each call.
     """
     backend = backend or HipBackend()
     torch = backend.torch
@@ -121,10 +124,16 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
 
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     cdev = getattr(backend, 'collective_device', backend.device)
-    counts = torch.zeros(world, dtype=torch.int64, device=cdev)
-    mine = torch.tensor([n_local], dtype=torch.int64, device=cdev)
-    dist.all_gather_into_tensor(counts, mine, group=group)
-    counts = counts.cpu().numpy()
+    if n_total is not None:
+        counts = np.array([shard_bounds(n_total, world, r)[1] - shard_bounds(n_total, world, r)[0] for r in range(world)],
+                          dtype=np.int64)
+        if int(counts[rank]) != n_local:
+            raise ValueError(f'rank {rank} of {world} must hold {int(counts[rank])} of {n_total} rows, got {n_local}')
+    else:
+        counts = torch.zeros(world, dtype=torch.int64, device=cdev)
+        mine = torch.tensor([n_local], dtype=torch.int64, device=cdev)
+        dist.all_gather_into_tensor(counts, mine, group=group)
+        counts = counts.cpu().numpy()
     n_total = int(counts.sum())
     per = int(counts.max())
     offsets = np.concatenate([[0], np.cumsum(counts)])

@@ -47,6 +47,15 @@ def main():
     lo, hi = pipeline.shard_bounds(n, world, rank)
     local = full.take(np.arange(lo, hi))
     res = pipeline.encode_and_knn(OracleEncoder('cont', e, g, 5), local, k, backend=OracleBackend())
+    # with the total known up front (no block-size exchange) the outcome is the same
+    res2 = pipeline.encode_and_knn(OracleEncoder('cont', e, g, 5), local, k, backend=OracleBackend(), n_total=n)
+    assert np.array_equal(res2['idx'], res['idx']) and np.array_equal(res2['dist'], res['dist'])
+    assert res2['q_begin'] == res['q_begin'] and res2['n_total'] == n
+    try:
+        pipeline.encode_and_knn(OracleEncoder('cont', e, g, 5), local, k, backend=OracleBackend(), n_total=n + world)
+        raise SystemExit('a wrong n_total went unnoticed')
+    except ValueError:
+        pass
     np.savez(os.path.join(out_dir, f'rank{rank}.npz'), enc=res['encodings'].numpy(), idx=res['idx'],
              dist=res['dist'], q_begin=res['q_begin'], n_total=res['n_total'], lo=lo, hi=hi)
     dist.barrier()
