@@ -14,7 +14,8 @@
  *     message of the last error on the calling thread is cc_last_error().
  *   - host buffers are caller-owned, C-contiguous, row-major.
  *   - `dev` pointers are HIP device pointers in the current process
- *     (e.g. torch.Tensor.data_ptr()).
+ *     (e.g. torch.Tensor.data_ptr()); whatever produced their contents on another
+ *     stream must have completed before the call (the library only orders its own work).
  *   - handles are opaque; free them with the matching *_free.
  *   - calls on one handle are not re-entrant; all work is issued on the
  *     library's own HIP stream and every call returns synchronised.
