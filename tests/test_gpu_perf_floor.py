@@ -1,0 +1,37 @@
+"""Performance floors for the hot kernels (generous: ~80 % of what round 1 measured).  They exist to catch silent
+regressions — a register spill or a different register assignment cost the layer-1 GEMM 11 % without changing a
+single result — not to certify the roofline numbers (bench.py and profiles/ do that)."""
+import numpy as np
+import pytest
+
+import cellcomm_amd as cc
+from cellcomm_amd import _lib, synth
+from cellcomm_amd.knn import knn_graph_device
+
+pytestmark = pytest.mark.gpu
+
+
+def test_kernel_rates_stay_above_their_floors(hip):
+    import torch
+    n, g, e = 8192, 30000, 64
+    m, _ = synth.synth_csr_device(n, g, seed=5)
+    enc = cc.HipEncoder(e, g, 'cont', seed=6)
+    out = torch.empty((n, e), device='cuda')
+    enc.predict_to_device(m, out.data_ptr(), 0, 8192)                     # warm-up: packs weights, allocates workspaces
+    _lib.profile_enable(True)
+    _lib.profile_reset()
+    try:
+        for _ in range(3):
+            enc.predict_to_device(m, out.data_ptr(), 0, 8192)             # one 8192-row pass: the launch shape of the bench
+        x = torch.rand((100000, 64), device='cuda')
+        torch.cuda.synchronize()
+        knn_graph_device(x.data_ptr(), 100000, 64, 15)
+        prof = _lib.profile_snapshot()
+    finally:
+        _lib.profile_enable(False)
+    rate = {k: v['work'] / (v['ms'] * 1e-3) for k, v in prof.items() if v['ms'] > 0}
+    assert rate['gemm_l1'] >= 110e12, f"layer-1 GEMM at {rate['gemm_l1'] / 1e12:.1f} TFLOP/s (round 1: 139)"
+    assert rate['gemm_l2'] >= 110e12, f"layer-2 GEMM at {rate['gemm_l2'] / 1e12:.1f} TFLOP/s (round 1: 139)"
+    assert rate['gather'] >= 4.5e12, f"gather at {rate['gather'] / 1e12:.2f} TB/s (round 1: 6.2)"
+    knn_ms = sum(prof[k]['ms'] for k in ('knn_pack', 'knn_select', 'knn_rerank'))
+    assert knn_ms <= 14.0, f'kNN kernels of a 100k x 100k call took {knn_ms:.1f} ms (round 1: 8.2)'
