@@ -1,4 +1,4 @@
-"""Performance floors for the hot kernels (generous: ~80 % of what round 1 measured).  They exist to catch silent
+"""Performance floors for the hot kernels (generous: ~75 % of what round 1 measured, so that a throttled box does not trip them).  They exist to catch silent
 regressions — a register spill or a different register assignment cost the layer-1 GEMM 11 % without changing a
 single result — not to certify the roofline numbers (bench.py and profiles/ do that)."""
 import numpy as np
@@ -30,8 +30,8 @@ def test_kernel_rates_stay_above_their_floors(hip):
     finally:
         _lib.profile_enable(False)
     rate = {k: v['work'] / (v['ms'] * 1e-3) for k, v in prof.items() if v['ms'] > 0}
-    assert rate['gemm_l1'] >= 110e12, f"layer-1 GEMM at {rate['gemm_l1'] / 1e12:.1f} TFLOP/s (round 1: 139)"
-    assert rate['gemm_l2'] >= 110e12, f"layer-2 GEMM at {rate['gemm_l2'] / 1e12:.1f} TFLOP/s (round 1: 139)"
-    assert rate['gather'] >= 4.5e12, f"gather at {rate['gather'] / 1e12:.2f} TB/s (round 1: 6.2)"
+    assert rate['gemm_l1'] >= 105e12, f"layer-1 GEMM at {rate['gemm_l1'] / 1e12:.1f} TFLOP/s (round 1: 139)"
+    assert rate['gemm_l2'] >= 105e12, f"layer-2 GEMM at {rate['gemm_l2'] / 1e12:.1f} TFLOP/s (round 1: 139)"
+    assert rate['gather'] >= 4.0e12, f"gather at {rate['gather'] / 1e12:.2f} TB/s (round 1: 6.2)"
     knn_ms = sum(prof[k]['ms'] for k in ('knn_pack', 'knn_select', 'knn_rerank'))
-    assert knn_ms <= 14.0, f'kNN kernels of a 100k x 100k call took {knn_ms:.1f} ms (round 1: 8.2)'
+    assert knn_ms <= 16.0, f'kNN kernels of a 100k x 100k call took {knn_ms:.1f} ms (round 1: 8.2)'
