@@ -253,12 +253,19 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   }
   const float *pa[NA];
   {
+#ifdef CC_GEMM_FAKE_A   // sensitivity probe: every workgroup reads the first m-tile's rows (results are wrong)
+    const int64_t m0 = 0;
+#endif
     const float *base = KT1 > 0 ? A1 + m0 * lda1 : A2 + m0 * lda2;
     const int lda = (int)(KT1 > 0 ? lda1 : lda2);
 #pragma unroll
     for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * lda + 4 * a_k4;
   }
+#ifdef CC_GEMM_FAKE_W   // sensitivity probe: every workgroup reads the first n-tile's weights (results are wrong)
+  const f32x4 *wt = Wp + tid;
+#else
   const f32x4 *wt = Wp + (int64_t)n_tile * KT * TILE_W_FLOAT4 + tid;
+#endif
 
   // The staging registers must stay in VGPRs (hipcc demotes them to scratch when
   // they are touched through lambdas or selected between arrays) so that the
