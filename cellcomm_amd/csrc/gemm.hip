@@ -143,7 +143,9 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA]
 #if CC_GEMM_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
+#ifndef CC_GEMM_FAKE_NOSYNC   // probe: no barriers, no LDS refill (results are wrong): the pure MFMA + fragment-read rate
     __syncthreads();
+#endif
     if (more) {
       float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;
 #pragma unroll
@@ -172,7 +174,9 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA]
         ps.pace_seen = __hip_atomic_load(ps.pace_grp + c + 1 - CC_GEMM_PACE_LEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 #endif
+#ifndef CC_GEMM_FAKE_NOSYNC
     __syncthreads();
+#endif
 #ifdef CC_GEMM_TRACE
     if (KCLASS == 1 && tid == 0 && bid < 16384 && kt == KT / 2) g_gemm_trace[4 * bid + 1] = wall_clock64();
 #endif
