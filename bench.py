@@ -7,11 +7,14 @@ BN -> 150 -> 150 -> 64, random Glorot weights), exact k=15 kNN on the encodings.
 A step = one pass of the whole hot path: device-resident CSR -> gather -> encoder
 -> (all-gather) -> kNN -> encodings + neighbour ids on the host.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W        (N > 1: starts its own N workers)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 With N > 1 the 100k cells are split into N contiguous blocks (strong scaling), one
-process per GPU, one RCCL all-gather of encodings per step.
+process per GPU, one RCCL all-gather of encodings per step.  Called without a
+torch.distributed environment, `--gpus N` launches `python -m torch.distributed.run`
+as a CHILD process before this process touches torch or the GPU, relays rank 0's
+JSON line and exits with the child's status.
 """
 import argparse
 import json
@@ -104,8 +107,37 @@ def cpu_baseline(args, enc, local, enc_host):
     }
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside torchrun: start the N workers as a child process group.
+    Nothing in this process has imported torch or touched HIP yet, and nothing will."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for out in proc.stdout:                     # rank 0 prints exactly one JSON line; anything else is chatter
+        text = out.strip()
+        if text.startswith('{') and '"metric"' in text:
+            line = text
+        elif text:
+            print(text, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: worker group exited with status {rc}')
+    if line is None:
+        raise SystemExit(f'bench.py --gpus {args.gpus}: workers finished without a result line')
+    print(line, flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return self_launch(args)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -114,9 +146,6 @@ def main():
     if os.environ.get('CC_BENCH_ONE_DEVICE'):   # rehearsal: several ranks share GPU 0 (1-GPU box), gloo collective
         local_rank = 0
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit(f'--gpus {args.gpus} needs one process per GPU: launch with '
-                             f'python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus}')
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
     torch.cuda.set_device(local_rank)
     if world > 1:

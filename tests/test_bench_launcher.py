@@ -1,0 +1,106 @@
+"""bench.py --gpus N outside torchrun starts its own workers as a child process.
+CPU part: the launcher builds the torch.distributed.run command, relays rank 0's JSON line and
+propagates a failing child — checked with a stand-in child.  GPU part (-m gpu): the real thing,
+two ranks sharing the one GPU of the test box (CC_BENCH_ONE_DEVICE rehearsal, gloo collective)."""
+import importlib.util
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+
+def load_bench():
+    spec = importlib.util.spec_from_file_location('bench_module', os.path.join(ROOT, 'bench.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class FakeChild:
+    def __init__(self, lines, rc):
+        self.stdout = iter(lines)
+        self._rc = rc
+
+    def wait(self):
+        return self._rc
+
+
+def run_launcher(monkeypatch, capsys, lines, rc, argv):
+    bench = load_bench()
+    seen = {}
+
+    def fake_popen(cmd, env=None, stdout=None, text=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return FakeChild(lines, rc)
+
+    monkeypatch.setattr(subprocess, 'Popen', fake_popen)
+    monkeypatch.setattr(sys, 'argv', ['bench.py'] + argv)
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    bench.main()
+    return seen, capsys.readouterr()
+
+
+def test_launcher_starts_torchrun_child_and_relays_the_line(monkeypatch, capsys):
+    line = json.dumps({'metric': 'm', 'value': 1.0, 'n_gpus': 4})
+    seen, io = run_launcher(monkeypatch, capsys, ['some warning\n', line + '\n'], 0,
+                            ['--gpus', '4', '--steps', '3', '--warmup', '1'])
+    cmd = seen['cmd']
+    assert cmd[:3] == [sys.executable, '-m', 'torch.distributed.run']
+    assert '--nproc-per-node=4' in cmd and '--nnodes=1' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert int(cmd[cmd.index('--master-port') + 1]) > 0
+    script = cmd.index(os.path.join(ROOT, 'bench.py'))
+    assert cmd[script + 1:] == ['--gpus', '4', '--steps', '3', '--warmup', '1']
+    assert seen['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    assert io.out.strip() == line                      # exactly the one JSON line on stdout
+    assert 'some warning' in io.err
+
+
+def test_launcher_propagates_a_failing_child(monkeypatch, capsys):
+    with pytest.raises(SystemExit) as err:
+        run_launcher(monkeypatch, capsys, ['boom\n'], 3, ['--gpus', '2'])
+    assert 'status 3' in str(err.value)
+
+
+def test_launcher_requires_a_result_line(monkeypatch, capsys):
+    with pytest.raises(SystemExit) as err:
+        run_launcher(monkeypatch, capsys, [], 0, ['--gpus', '2'])
+    assert 'without a result line' in str(err.value)
+
+
+def test_launcher_parent_does_not_import_torch():
+    """The parent must not touch torch / HIP before (or after) it starts the workers."""
+    code = ('import sys, subprocess, types\n'
+            'class C:\n'
+            '    stdout = iter([\'{"metric": "x", "n_gpus": 2}\\n\'])\n'
+            '    def wait(self): return 0\n'
+            'subprocess.Popen = lambda *a, **k: C()\n'
+            f'sys.argv = ["bench.py", "--gpus", "2"]\n'
+            f'sys.path.insert(0, {ROOT!r})\n'
+            'import runpy\n'
+            f'runpy.run_path({os.path.join(ROOT, "bench.py")!r}, run_name="__main__")\n'
+            'assert "torch" not in sys.modules, "launcher imported torch"\n'
+            'assert "cellcomm_amd" not in sys.modules\n')
+    env = {k: v for k, v in os.environ.items() if k != 'WORLD_SIZE'}
+    proc = subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, env=env, timeout=120)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert json.loads(proc.stdout.strip())['n_gpus'] == 2
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_self_launch_on_one_device(hip):
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(CC_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                           '--cells', '6000', '--genes', '2000', '--latent', '32', '--no-cpu-baseline', '--no-alt'],
+                          capture_output=True, text=True, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, proc.stdout
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['steps'] == 2 and res['value'] > 0
+    assert res['config']['cells'] == 6000

@@ -1,0 +1,310 @@
+// Prototype (not part of the product): sparse-aware encoder layer 1.
+//   H[M x N] = sigmoid(X_csr[M x K] @ W[K x N] + b),  X 5 % dense, exact fp32 FMAs on the vector ALUs.
+// Reference shape: /root/reference/src/bigan_cont.py:32 (Dense(int(G*0.1), sigmoid) on the raw counts).
+//
+//   hipcc --offload-arch=gfx950 -O3 tools/experiments/spmm_l1.hip -o /tmp/spmm_l1 && /tmp/spmm_l1 [M] [K] [N] [variant]
+//
+// Structure.  One 1024-thread workgroup owns 256 rows x 256 output columns: wave w holds rows 16w..16w+15, lane l the
+// four columns 4l..4l+3 of each -> 64 accumulator registers per lane.  The weight panel W[:, 256 columns] streams
+// through LDS in stages of 64 k-rows (64 KiB, LDS-DMA, double buffered, one barrier per stage) and is shared by the
+// 256 rows; per non-zero (row, k, v) a wave issues ONE ds_read_b128 (its 4 weights of k-row k) and 4 v_fma_f32.
+// The non-zeros arrive as a per-wave stream sorted by (stage, row): entry = {code, value}, code = k_local*1024
+// (byte offset of the k-row in the LDS stage) | (row_local*4) << 16 (accumulator register offset); 64 entries at a
+// time sit in two VGPRs and are picked out with v_readlane.
+//
+// The accumulator of a non-zero's row is selected at run time:
+//   variant 0: VGPR index mode (s_set_gpr_idx_on, dst + src2 relative) around the four FMAs; accumulators are
+//              pinned to v[64:127].  One straight loop over a wave's entries of a stage.
+//   variant 1: no index mode: a static loop over the wave's 16 rows, each with a dynamic loop over that row's
+//              entries of the stage (entries are sorted by row within a stage).
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int ROWS = 256, WAVES = 16, RW = 16, KB = 64, NT = 256, THREADS = 1024;
+constexpr int STAGE_BYTES = KB * NT * 4;   // 64 KiB
+
+#define GLDS(src, dst) \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src), \
+                                   (void __attribute__((address_space(3))) *)(dst), 16, 0, 0)
+
+struct Entry { uint32_t code; float val; };
+
+__device__ __forceinline__ f32x4 lds_read4(const char *p) { return *reinterpret_cast<const f32x4 *>(p); }
+
+// acc[(idx..idx+3)] += v * b   with idx = 4 * row_local, accumulators pinned at v[64:127]
+#define FMA4_IDX(acc0, acc1, idx, v, b)                                                      \
+  do {                                                                                       \
+    int m0_save_;                                                                            \
+    asm volatile("s_mov_b32 %2, m0\n\t"                                                      \
+                 "s_set_gpr_idx_on %3, 0xc\n\t"                                              \
+                 "v_fma_f32 v64, %4, %5, v64\n\t"                                            \
+                 "v_fma_f32 v65, %4, %6, v65\n\t"                                            \
+                 "v_fma_f32 v66, %4, %7, v66\n\t"                                            \
+                 "v_fma_f32 v67, %4, %8, v67\n\t"                                            \
+                 "s_set_gpr_idx_off\n\t"                                                     \
+                 "s_mov_b32 m0, %2\n\t"                                                      \
+                 "s_nop 0"                                                                   \
+                 : "+{v[64:95]}"(acc0), "+{v[96:127]}"(acc1), "=&s"(m0_save_)                \
+                 : "s"(idx), "s"(v), "v"((b).x), "v"((b).y), "v"((b).z), "v"((b).w));        \
+  } while (0)
+
+constexpr int ENT_BYTES = 1024;                                  // per wave and stage parity: up to 128 entries
+constexpr int LDS_BYTES = 2 * STAGE_BYTES + 2 * WAVES * ENT_BYTES;  // 160 KiB: the whole LDS of a CU
+
+template <int VARIANT>
+__global__ __launch_bounds__(THREADS, 1) void spmm_kernel(const Entry *__restrict__ ent, const int *__restrict__ offs,
+                                                          const float *__restrict__ Wp, const float *__restrict__ bias,
+                                                          int K, int nstages, int nrb, float *__restrict__ out,
+                                                          int64_t ldo) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int panel = blockIdx.x / nrb, rb = blockIdx.x % nrb;
+  const float *wsrc = Wp + (int64_t)panel * K * NT + lane * 4;   // + k * NT
+  const int *my_offs = offs + (int64_t)(rb * WAVES + wave) * (nstages + 1);
+  char *ent_lds = smem + 2 * STAGE_BYTES + wave * (2 * ENT_BYTES);
+
+  f32x32 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+  // stage s: 64 k-rows of the weight panel (4 per wave) + this wave's entries of the stage (<= 128, 2 per lane)
+  auto issue = [&](int s, int buf, int first) {
+    char *dst = smem + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < KB / WAVES; ++i) {
+      const int kl = i * WAVES + wave;
+      int k = s * KB + kl;
+      k = k < K ? k : K - 1;   // rows beyond K are never referenced by an entry
+      GLDS(wsrc + (int64_t)k * NT, dst + kl * (NT * 4));
+    }
+    GLDS(ent + first + 2 * lane, ent_lds + buf * ENT_BYTES);
+  };
+
+  int pos = my_offs[0];
+  issue(0, 0, pos);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int lane16 = lane * 16;
+  for (int s = 0; s < nstages; ++s) {
+    const int end = my_offs[s + 1];
+    if (s + 1 < nstages) issue(s + 1, (s + 1) & 1, end);
+    const char *bbase = smem + (s & 1) * STAGE_BYTES + lane16;
+    const char *ebase = ent_lds + (s & 1) * ENT_BYTES + lane * 8;
+    const int n = end - pos;   // <= 128 (checked when the stream is built)
+    pos = end;
+    for (int c0 = 0; c0 < n; c0 += 64) {
+      const Entry cur = *reinterpret_cast<const Entry *>(ebase + c0 * 8);
+      const int m = n - c0 < 64 ? n - c0 : 64;
+      if (VARIANT == 0) {
+        int i = 0;
+        for (; i + 4 <= m; i += 4) {
+          uint32_t c0_ = __builtin_amdgcn_readlane(cur.code, i), c1 = __builtin_amdgcn_readlane(cur.code, i + 1);
+          uint32_t c2 = __builtin_amdgcn_readlane(cur.code, i + 2), c3 = __builtin_amdgcn_readlane(cur.code, i + 3);
+          f32x4 b0 = lds_read4(bbase + (c0_ & 0xffff)), b1 = lds_read4(bbase + (c1 & 0xffff));
+          f32x4 b2 = lds_read4(bbase + (c2 & 0xffff)), b3 = lds_read4(bbase + (c3 & 0xffff));
+          float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i));
+          float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i + 1));
+          float v2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i + 2));
+          float v3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i + 3));
+          FMA4_IDX(acc0, acc1, c0_ >> 16, v0, b0);
+          FMA4_IDX(acc0, acc1, c1 >> 16, v1, b1);
+          FMA4_IDX(acc0, acc1, c2 >> 16, v2, b2);
+          FMA4_IDX(acc0, acc1, c3 >> 16, v3, b3);
+        }
+        for (; i < m; ++i) {
+          uint32_t c0_ = __builtin_amdgcn_readlane(cur.code, i);
+          f32x4 b0 = lds_read4(bbase + (c0_ & 0xffff));
+          float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i));
+          FMA4_IDX(acc0, acc1, c0_ >> 16, v0, b0);
+        }
+      } else {
+        int i = 0;
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+          while (i < m) {
+            const uint32_t cc = __builtin_amdgcn_readlane(cur.code, i);
+            if ((int)(cc >> 18) != r) break;
+            const f32x4 b0 = lds_read4(bbase + (cc & 0xffff));
+            const float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i));
+            if (r < 8) {
+              acc0[4 * (r & 7) + 0] += v0 * b0.x; acc0[4 * (r & 7) + 1] += v0 * b0.y;
+              acc0[4 * (r & 7) + 2] += v0 * b0.z; acc0[4 * (r & 7) + 3] += v0 * b0.w;
+            } else {
+              acc1[4 * (r & 7) + 0] += v0 * b0.x; acc1[4 * (r & 7) + 1] += v0 * b0.y;
+              acc1[4 * (r & 7) + 2] += v0 * b0.z; acc1[4 * (r & 7) + 3] += v0 * b0.w;
+            }
+            ++i;
+          }
+        }
+        // a 64-entry window may end inside a row: the static row loop above stops at the first row change only,
+        // so entries left over (rows restart in the next window) cannot occur: windows are consumed fully
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // epilogue: bias + sigmoid, 1 KiB per row per wave
+  const int col = panel * NT + lane * 4;
+  const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + col);
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int64_t row = (int64_t)rb * ROWS + wave * RW + r;
+    f32x4 z;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = (r < 8 ? acc0[4 * (r & 7) + j] : acc1[4 * (r & 7) + j]) + bv[j];
+      z[j] = 1.f / (1.f + __expf(-a));
+    }
+    if (col + 3 < ldo) *reinterpret_cast<f32x4 *>(out + row * ldo + col) = z;
+  }
+}
+
+int main(int argc, char **argv) {
+  const int M = argc > 1 ? atoi(argv[1]) : 32768;
+  const int K = argc > 2 ? atoi(argv[2]) : 30000;
+  const int N = argc > 3 ? atoi(argv[3]) : 3000;
+  const int variant = argc > 4 ? atoi(argv[4]) : 0;
+  const double density = 0.05;
+  if (M % ROWS) { printf("M must be a multiple of %d\n", ROWS); return 1; }
+  const int nrb = M / ROWS, npan = (N + NT - 1) / NT, nstages = (K + KB - 1) / KB;
+  const int64_t ldo = (int64_t)npan * NT;
+
+  // synthetic CSR: Binomial(K, 0.05) sorted distinct columns per row, values 1 + Geometric
+  std::mt19937_64 rng(1234);
+  std::vector<int64_t> indptr(M + 1, 0);
+  std::vector<int32_t> cols;
+  std::vector<float> vals;
+  cols.reserve((size_t)(M * K * density * 1.02));
+  vals.reserve(cols.capacity());
+  std::uniform_real_distribution<double> U(0.0, 1.0);
+  std::geometric_distribution<int> geo(0.5);
+  for (int i = 0; i < M; ++i) {
+    // skip sampling: gaps ~ Geometric(density)
+    int k = -1;
+    for (;;) {
+      const double u = U(rng);
+      k += 1 + (int)std::floor(std::log(1.0 - u) / std::log(1.0 - density));
+      if (k >= K) break;
+      cols.push_back(k);
+      vals.push_back((float)std::min(1 + geo(rng), 2047));
+    }
+    indptr[i + 1] = (int64_t)cols.size();
+  }
+  const int64_t nnz = (int64_t)cols.size();
+  printf("M=%d K=%d N=%d nnz=%lld (%.2f%%) variant=%d\n", M, K, N, (long long)nnz, 100.0 * nnz / ((double)M * K), variant);
+
+  // weights (Glorot-uniform) and bias
+  std::vector<float> W((size_t)K * N), b(ldo, 0.f);
+  {
+    const float lim = std::sqrt(6.0f / (K + N));
+    std::uniform_real_distribution<float> D(-lim, lim);
+    for (auto &w : W) w = D(rng);
+    std::uniform_real_distribution<float> B(-0.5f, 0.5f);
+    for (int j = 0; j < N; ++j) b[j] = B(rng);
+  }
+  std::vector<float> Wp((size_t)npan * K * NT, 0.f);
+  for (int p = 0; p < npan; ++p)
+    for (int k = 0; k < K; ++k)
+      for (int j = 0; j < NT && p * NT + j < N; ++j) Wp[((size_t)p * K + k) * NT + j] = W[(size_t)k * N + p * NT + j];
+
+  // per-wave entry streams sorted by (stage, row, k); every (wave, stage) list starts at an even stream index
+  // (16-byte aligned for the LDS-DMA) and holds at most 128 entries
+  std::vector<Entry> ent;
+  std::vector<int> offs((size_t)nrb * WAVES * (nstages + 1));
+  ent.reserve((size_t)nnz + (size_t)nrb * WAVES * nstages + 512);
+  std::vector<int64_t> cursor(RW);
+  size_t max_cnt = 0;
+  for (int rbw = 0; rbw < nrb * WAVES; ++rbw) {
+    const int64_t row0 = (int64_t)rbw * RW;
+    for (int r = 0; r < RW; ++r) cursor[r] = indptr[row0 + r];
+    for (int s = 0; s < nstages; ++s) {
+      if (ent.size() & 1) ent.push_back({0u, 0.f});
+      offs[(size_t)rbw * (nstages + 1) + s] = (int)ent.size();
+      const size_t start = ent.size();
+      const int kend = (s + 1) * KB;
+      for (int r = 0; r < RW; ++r) {
+        int64_t &c = cursor[r];
+        while (c < indptr[row0 + r + 1] && cols[c] < kend) {
+          ent.push_back({(uint32_t)((cols[c] - s * KB) * (NT * 4)) | ((uint32_t)(r * 4) << 16), vals[c]});
+          ++c;
+        }
+      }
+      max_cnt = std::max(max_cnt, ent.size() - start);
+    }
+    if (ent.size() & 1) ent.push_back({0u, 0.f});
+    offs[(size_t)rbw * (nstages + 1) + nstages] = (int)ent.size();
+  }
+  for (int i = 0; i < 256; ++i) ent.push_back({0u, 0.f});   // the DMA of a stage always moves 128 entries
+  printf("entries per (wave, stage): mean %.1f max %zu\n", (double)nnz / ((double)nrb * WAVES * nstages), max_cnt);
+  if (max_cnt > 128) { printf("a (wave, stage) list exceeds 128 entries\n"); return 1; }
+  if (ent.size() > 0x7fffffffull) { printf("stream too long for int offsets\n"); return 1; }
+
+  Entry *d_ent; int *d_offs; float *d_Wp, *d_b, *d_out;
+  CHECK(hipMalloc(&d_ent, ent.size() * sizeof(Entry)));
+  CHECK(hipMalloc(&d_offs, offs.size() * sizeof(int)));
+  CHECK(hipMalloc(&d_Wp, Wp.size() * sizeof(float)));
+  CHECK(hipMalloc(&d_b, b.size() * sizeof(float)));
+  CHECK(hipMalloc(&d_out, (size_t)M * ldo * sizeof(float)));
+  CHECK(hipMemcpy(d_ent, ent.data(), ent.size() * sizeof(Entry), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_offs, offs.data(), offs.size() * sizeof(int), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_Wp, Wp.data(), Wp.size() * sizeof(float), hipMemcpyHostToDevice));
+  CHECK(hipMemcpy(d_b, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
+  CHECK(hipMemset(d_out, 0, (size_t)M * ldo * sizeof(float)));
+
+  auto kern = variant == 0 ? spmm_kernel<0> : spmm_kernel<1>;
+  CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  hipEvent_t e0, e1;
+  CHECK(hipEventCreate(&e0));
+  CHECK(hipEventCreate(&e1));
+  const int grid = nrb * npan;
+  float best = 1e30f;
+  for (int it = 0; it < 4; ++it) {
+    CHECK(hipEventRecord(e0));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, 0, d_ent, d_offs, d_Wp, d_b, K, nstages, nrb, d_out, ldo);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipEventSynchronize(e1));
+    CHECK(hipGetLastError());
+    float ms = 0;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("  launch %d: %.3f ms\n", it, ms);
+    if (it > 0 && ms < best) best = ms;
+  }
+  const double flop = 2.0 * (double)nnz * N;
+  printf("best %.3f ms for %d rows -> %.1f ms per 100k cells; %.1f TFLOP/s on the non-zero products; dense-equivalent %.0f TFLOP/s\n",
+         best, M, best * 100000.0 / M, flop / (best * 1e-3) / 1e12, 2.0 * M * (double)K * N / (best * 1e-3) / 1e12);
+
+  // check sampled rows against float64
+  std::vector<float> out((size_t)M * ldo);
+  CHECK(hipMemcpy(out.data(), d_out, out.size() * sizeof(float), hipMemcpyDeviceToHost));
+  double worst = 0;
+  const int samples[] = {0, 1, 15, 16, 255, 256, M / 2 + 3, M - 1};
+  for (int row : samples) {
+    std::vector<double> z(N);
+    for (int j = 0; j < N; ++j) z[j] = b[j];
+    for (int64_t p = indptr[row]; p < indptr[row + 1]; ++p) {
+      const float *wr = &W[(size_t)cols[p] * N];
+      for (int j = 0; j < N; ++j) z[j] += (double)vals[p] * (double)wr[j];
+    }
+    for (int j = 0; j < N; ++j) {
+      const double t = 1.0 / (1.0 + std::exp(-z[j]));
+      const double rel = std::fabs((double)out[(size_t)row * ldo + j] - t) / t;
+      if (rel > worst) worst = rel;
+    }
+  }
+  printf("max relative error vs float64 on %zu sampled rows: %.3e %s\n", sizeof(samples) / sizeof(int), worst,
+         worst <= 1e-4 ? "OK" : "FAIL");
+  return worst <= 1e-4 ? 0 : 2;
+}
