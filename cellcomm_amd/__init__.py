@@ -13,3 +13,4 @@ from .generator import HipGenerator, build_cont_generator, build_classify_genera
 from .bigan import BasicBiGan, ClassifyCellBiGan, ContinuousCellBiGan  # noqa: F401
 from .training import CellTraining  # noqa: F401
 from .knn import knn_graph  # noqa: F401
+from .recorder import DbRecorder, MemoryDatabase  # noqa: F401

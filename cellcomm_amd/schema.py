@@ -4,11 +4,15 @@
   import_encodings.py:24-63 (``{_id, pids, ns, xs, ys, zs}``, coords = enc x 255).
 * ``encits`` document: reference src/intercepts/db_recorder.py:82-121 /
   db_schema.js:14-26 (``{eid, it, cids, ns, xs, ys, zs, ds}``).
+* run-level ``encs`` document ``{_id, date, defit, showits, srcs}``: reference
+  src/intercepts/db_recorder.py:48-64 (the first thing cellan fetches,
+  cellan/backend/apiRouter.js:8-15); `recorder.DbRecorder` keeps it up to date.
 * optional additive fields ``nn`` / ``nd`` carry the kNN graph; cellan ignores
   unknown fields (reference cellan/backend/apiRouter.js:17-25).
 """
 import pickle
 from collections import defaultdict
+from datetime import datetime
 
 import numpy as np
 import pandas as pd
@@ -79,6 +83,38 @@ def encits_document(enc_run_id, it, encodings, barcodes, knn=None):
         doc['nn'] = (np.asarray(idx) + 1).tolist()       # 1-based like cids
         doc['nd'] = np.asarray(dist).tolist()
     return doc
+
+
+def encits_from_wide(enc_run_id, it, encodings, barcodes, dims=(0, 1, 2), knn=None):
+    """`encits` document of encodings wider than 3 (E = 32 / 64 in BASELINE configs[1..4]): the viewer plots exactly
+    three coordinates (reference db_recorder.py:89-90 asserts width 3), so three latent dimensions are exported —
+    by default dims 0..2, as import_encodings.py:44-54 does for the legacy document — while `knn` (computed on the
+    full-width encodings) rides along unchanged."""
+    encodings = np.asarray(encodings)
+    assert encodings.ndim == 2 and len(dims) == 3, 'dims must name three latent dimensions'
+    assert all(0 <= d < encodings.shape[1] for d in dims), \
+        f'dims {tuple(dims)} outside encodings of width {encodings.shape[1]}'
+    return encits_document(enc_run_id, it, encodings[:, list(dims)], barcodes, knn=knn)
+
+
+def encs_run_document(enc_run_id, sources, now=None):
+    """The run-level document of the `encs` collection (reference db_recorder.py:48-64, pinned by
+    test/db_recorder_test.py:41-52): created once per run with `defit` 0 and no `showits`; the recorder's
+    interceptor then sets `defit` to the latest iteration and appends to `showits` (db_recorder.py:104-108).
+    `sources` = {'matrix', 'barcodes', 'genes'} paths; only their file names are stored."""
+    def file_name(full_path):
+        return full_path.split('/')[-1]
+    return {
+        '_id': enc_run_id,
+        'date': now if now is not None else datetime.now(),
+        'defit': 0,
+        'showits': [],
+        'srcs': {
+            'matrix': file_name(sources['matrix']),
+            'barcodes': file_name(sources['barcodes']),
+            'genes': file_name(sources['genes']),
+        },
+    }
 
 
 def legacy_encs_document(iteration, encodings, barcodes):

@@ -59,6 +59,42 @@ __device__ __forceinline__ f32x4 lds_read4(const char *p) { return *reinterpret_
                  : "s"(idx), "s"(v), "v"((b).x), "v"((b).y), "v"((b).z), "v"((b).w));        \
   } while (0)
 
+// four entries under one index-mode bracket (s_set_gpr_idx_idx moves the index between them)
+#define FMA16_IDX(acc0, acc1, i0, i1, i2, i3, v0, v1, v2, v3, b0, b1, b2, b3)                          \
+  do {                                                                                                 \
+    int m0_save_;                                                                                      \
+    asm volatile("s_mov_b32 %2, m0\n\t"                                                                \
+                 "s_set_gpr_idx_on %3, 0xc\n\t"                                                        \
+                 "v_fma_f32 v64, %7, %11, v64\n\t"                                                     \
+                 "v_fma_f32 v65, %7, %12, v65\n\t"                                                     \
+                 "v_fma_f32 v66, %7, %13, v66\n\t"                                                     \
+                 "v_fma_f32 v67, %7, %14, v67\n\t"                                                     \
+                 "s_set_gpr_idx_idx %4\n\t"                                                            \
+                 "v_fma_f32 v64, %8, %15, v64\n\t"                                                     \
+                 "v_fma_f32 v65, %8, %16, v65\n\t"                                                     \
+                 "v_fma_f32 v66, %8, %17, v66\n\t"                                                     \
+                 "v_fma_f32 v67, %8, %18, v67\n\t"                                                     \
+                 "s_set_gpr_idx_idx %5\n\t"                                                            \
+                 "v_fma_f32 v64, %9, %19, v64\n\t"                                                     \
+                 "v_fma_f32 v65, %9, %20, v65\n\t"                                                     \
+                 "v_fma_f32 v66, %9, %21, v66\n\t"                                                     \
+                 "v_fma_f32 v67, %9, %22, v67\n\t"                                                     \
+                 "s_set_gpr_idx_idx %6\n\t"                                                            \
+                 "v_fma_f32 v64, %10, %23, v64\n\t"                                                    \
+                 "v_fma_f32 v65, %10, %24, v65\n\t"                                                    \
+                 "v_fma_f32 v66, %10, %25, v66\n\t"                                                    \
+                 "v_fma_f32 v67, %10, %26, v67\n\t"                                                    \
+                 "s_set_gpr_idx_off\n\t"                                                               \
+                 "s_mov_b32 m0, %2\n\t"                                                                \
+                 "s_nop 0"                                                                             \
+                 : "+{v[64:95]}"(acc0), "+{v[96:127]}"(acc1), "=&s"(m0_save_)                          \
+                 : "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(v0), "s"(v1), "s"(v2), "s"(v3),             \
+                   "v"((b0).x), "v"((b0).y), "v"((b0).z), "v"((b0).w),                                 \
+                   "v"((b1).x), "v"((b1).y), "v"((b1).z), "v"((b1).w),                                 \
+                   "v"((b2).x), "v"((b2).y), "v"((b2).z), "v"((b2).w),                                 \
+                   "v"((b3).x), "v"((b3).y), "v"((b3).z), "v"((b3).w));                                \
+  } while (0)
+
 constexpr int ENT_BYTES = 1024;                                  // per wave and stage parity: up to 128 entries
 constexpr int LDS_BYTES = 2 * STAGE_BYTES + 2 * WAVES * ENT_BYTES;  // 160 KiB: the whole LDS of a CU
 
@@ -107,26 +143,43 @@ __global__ __launch_bounds__(THREADS, 1) void spmm_kernel(const Entry *__restric
     for (int c0 = 0; c0 < n; c0 += 64) {
       const Entry cur = *reinterpret_cast<const Entry *>(ebase + c0 * 8);
       const int m = n - c0 < 64 ? n - c0 : 64;
-      if (VARIANT == 0) {
+      if (VARIANT == 0 || VARIANT == 2) {
         int i = 0;
+#define RL_CODE(j) __builtin_amdgcn_readlane(cur.code, (j))
+#define RL_VAL(j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), (j)))
+        if (VARIANT == 2) {
+          // 8 entries per trip: both groups' weight reads are issued before the first group's FMAs
+          for (; i + 8 <= m; i += 8) {
+            uint32_t c0_ = RL_CODE(i), c1 = RL_CODE(i + 1), c2 = RL_CODE(i + 2), c3 = RL_CODE(i + 3);
+            uint32_t c4 = RL_CODE(i + 4), c5 = RL_CODE(i + 5), c6 = RL_CODE(i + 6), c7 = RL_CODE(i + 7);
+            f32x4 b0 = lds_read4(bbase + (c0_ & 0xffff)), b1 = lds_read4(bbase + (c1 & 0xffff));
+            f32x4 b2 = lds_read4(bbase + (c2 & 0xffff)), b3 = lds_read4(bbase + (c3 & 0xffff));
+            f32x4 b4 = lds_read4(bbase + (c4 & 0xffff)), b5 = lds_read4(bbase + (c5 & 0xffff));
+            f32x4 b6 = lds_read4(bbase + (c6 & 0xffff)), b7 = lds_read4(bbase + (c7 & 0xffff));
+            float v0 = RL_VAL(i), v1 = RL_VAL(i + 1), v2 = RL_VAL(i + 2), v3 = RL_VAL(i + 3);
+            float v4 = RL_VAL(i + 4), v5 = RL_VAL(i + 5), v6 = RL_VAL(i + 6), v7 = RL_VAL(i + 7);
+            FMA16_IDX(acc0, acc1, c0_ >> 16, c1 >> 16, c2 >> 16, c3 >> 16, v0, v1, v2, v3, b0, b1, b2, b3);
+            FMA16_IDX(acc0, acc1, c4 >> 16, c5 >> 16, c6 >> 16, c7 >> 16, v4, v5, v6, v7, b4, b5, b6, b7);
+          }
+        }
         for (; i + 4 <= m; i += 4) {
-          uint32_t c0_ = __builtin_amdgcn_readlane(cur.code, i), c1 = __builtin_amdgcn_readlane(cur.code, i + 1);
-          uint32_t c2 = __builtin_amdgcn_readlane(cur.code, i + 2), c3 = __builtin_amdgcn_readlane(cur.code, i + 3);
+          uint32_t c0_ = RL_CODE(i), c1 = RL_CODE(i + 1), c2 = RL_CODE(i + 2), c3 = RL_CODE(i + 3);
           f32x4 b0 = lds_read4(bbase + (c0_ & 0xffff)), b1 = lds_read4(bbase + (c1 & 0xffff));
           f32x4 b2 = lds_read4(bbase + (c2 & 0xffff)), b3 = lds_read4(bbase + (c3 & 0xffff));
-          float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i));
-          float v1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i + 1));
-          float v2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i + 2));
-          float v3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i + 3));
-          FMA4_IDX(acc0, acc1, c0_ >> 16, v0, b0);
-          FMA4_IDX(acc0, acc1, c1 >> 16, v1, b1);
-          FMA4_IDX(acc0, acc1, c2 >> 16, v2, b2);
-          FMA4_IDX(acc0, acc1, c3 >> 16, v3, b3);
+          float v0 = RL_VAL(i), v1 = RL_VAL(i + 1), v2 = RL_VAL(i + 2), v3 = RL_VAL(i + 3);
+          if (VARIANT == 2) {
+            FMA16_IDX(acc0, acc1, c0_ >> 16, c1 >> 16, c2 >> 16, c3 >> 16, v0, v1, v2, v3, b0, b1, b2, b3);
+          } else {
+            FMA4_IDX(acc0, acc1, c0_ >> 16, v0, b0);
+            FMA4_IDX(acc0, acc1, c1 >> 16, v1, b1);
+            FMA4_IDX(acc0, acc1, c2 >> 16, v2, b2);
+            FMA4_IDX(acc0, acc1, c3 >> 16, v3, b3);
+          }
         }
         for (; i < m; ++i) {
-          uint32_t c0_ = __builtin_amdgcn_readlane(cur.code, i);
+          uint32_t c0_ = RL_CODE(i);
           f32x4 b0 = lds_read4(bbase + (c0_ & 0xffff));
-          float v0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), i));
+          float v0 = RL_VAL(i);
           FMA4_IDX(acc0, acc1, c0_ >> 16, v0, b0);
         }
       } else {
@@ -264,7 +317,7 @@ int main(int argc, char **argv) {
   CHECK(hipMemcpy(d_b, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
   CHECK(hipMemset(d_out, 0, (size_t)M * ldo * sizeof(float)));
 
-  auto kern = variant == 0 ? spmm_kernel<0> : spmm_kernel<1>;
+  auto kern = variant == 0 ? spmm_kernel<0> : variant == 1 ? spmm_kernel<1> : spmm_kernel<2>;
   CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
