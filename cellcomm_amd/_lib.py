@@ -29,6 +29,7 @@ def lib_path():
 # name -> (restype, argtypes); must list every symbol declared in include/cellcomm_hip.h
 SIGNATURES = {
     'cc_init': (c_int, [c_int]),
+    'cc_shutdown': (c_int, []),
     'cc_version': (c_int, []),
     'cc_last_error': (c_char_p, []),
     'cc_device_count': (c_int, []),
@@ -60,6 +61,11 @@ SIGNATURES = {
     'cc_mtx_free': (None, [c_void_p]),
     'cc_knn_l2': (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_void_p]),
     'cc_knn_l2_dev': (c_int, [c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    'cc_knn_create': (c_int, [POINTER(c_void_p)]),
+    'cc_knn_free': (None, [c_void_p]),
+    'cc_knn_search_dev': (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_void_p]),
+    'cc_knn_set_option': (c_int, [c_void_p, c_int, c_int]),
+    'cc_knn_stat': (c_int, [c_void_p, c_int, POINTER(c_int64)]),
     'cc_knn_force_fallback': (c_int, [c_int]),
     'cc_knn_force_full_select': (c_int, [c_int]),
     'cc_knn_use_fp16_collect': (c_int, [c_int]),
@@ -125,6 +131,16 @@ def ensure_init(device=None):
         raise HipUnavailable(handle.cc_last_error().decode('utf-8', 'replace'))
     _INIT_DEVICE = device
     return handle
+
+
+def shutdown():
+    """Release the library context (streams, pooled events, default kNN scratch).  Handles created by the
+    caller (encoders, matrices, kNN workspaces) must have been freed first; afterwards `ensure_init` may
+    bind another device."""
+    global _INIT_DEVICE
+    if _LIB is not None:
+        check(_LIB.cc_shutdown())
+    _INIT_DEVICE = None
 
 
 def profile_enable(on=True):

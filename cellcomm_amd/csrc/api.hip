@@ -13,6 +13,8 @@ static thread_local std::string g_err;
 static hipStream_t g_stream = nullptr;    // the library stream
 static hipStream_t g_stream2 = nullptr;   // second stream: alternate passes of a short encode call run on it
 static hipStream_t g_cur = nullptr;       // stream the launchers currently issue on (g_stream unless overridden)
+static hipEvent_t g_lead_done = nullptr;  // orders the overlapped pass pair of a short encode call behind its full passes
+static hipEvent_t g_slot_free[2] = {nullptr, nullptr}, g_slot_full[2] = {nullptr, nullptr};   // cc_encode_dense pipeline
 static int g_device = -1;
 
 void set_error(const char *fmt, ...) {
@@ -319,6 +321,11 @@ static int encoder_forward(Encoder *e, int sl, int64_t M, float *out, float *h2_
   return CC_OK;
 }
 
+// gather.hip / convert: bit 0 = some value is not an fp16 number, bit 1 = a finite value left the fp16 range (or NaN)
+static bool fp16_pass_needs_fp32(int dtype, int flag) {
+  return dtype == CC_DTYPE_F16X2 ? flag != 0 : (flag & 2) != 0;
+}
+
 static int check_rows(const Csr *c, const int64_t *row_ids, int64_t row_start, int64_t n) {
   CC_REQUIRE(n >= 0, "negative row count");
   if (row_ids) {
@@ -383,17 +390,15 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
     e->tail_rows = n;
   }
   if (dual) CC_HIP(hipStreamSynchronize(g_stream));   // workspace / h2_all memsets are on the library stream
-  struct StreamReset { ~StreamReset() { g_cur = nullptr; g_gemm_pace = false; } } stream_reset;
-  g_gemm_pace = !dual;
-  static hipEvent_t lead_done = nullptr;
-  if (lead_passes > 0 && !lead_done) CC_HIP(hipEventCreateWithFlags(&lead_done, hipEventDisableTiming));
+  struct StreamReset { ~StreamReset() { g_cur = nullptr; } } stream_reset;
+  if (lead_passes > 0 && !g_lead_done) CC_HIP(hipEventCreateWithFlags(&g_lead_done, hipEventDisableTiming));
   int64_t pass_no = 0;
   for (const Pass &ps : plan) {
     const int sl = ps.slot;
     const int64_t off = ps.off, m = ps.m;
     if (lead_passes > 0 && pass_no == lead_passes) {   // the overlapped pair starts together, after the full passes
-      CC_HIP(hipEventRecord(lead_done, g_stream));
-      CC_HIP(hipStreamWaitEvent(g_stream2, lead_done, 0));
+      CC_HIP(hipEventRecord(g_lead_done, g_stream));
+      CC_HIP(hipStreamWaitEvent(g_stream2, g_lead_done, 0));
     }
     ++pass_no;
     g_cur = sl ? g_stream2 : g_stream;
@@ -408,11 +413,11 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
       if ((rc = launch_gather_f16(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start + off, m, e->G,
                                   e->ldxh, e->xh[sl], e->d_flag[sl], nnz_per_row * (double)m)))
         return rc;
-      if (e->dtype == CC_DTYPE_F16X2) {   // the 2-term raw-input product needs fp16-exact values
+      {   // f16x2: the 2-term raw-input product needs fp16-exact values; f16: values must stay inside the fp16 range
         int flag = 0;
         CC_HIP(hipMemcpyAsync(&flag, e->d_flag[sl], sizeof(int), hipMemcpyDeviceToHost, stream()));
         CC_HIP(hipStreamSynchronize(stream()));
-        if (flag) { fp32_pass = true; e->fallback_passes += 1; }
+        if (fp16_pass_needs_fp32(e->dtype, flag)) { fp32_pass = true; e->fallback_passes += 1; }
       }
       if (!fp32_pass && (rc = encoder_forward16(e, sl, m, dev_out + off * e->E, tail_once ? e->h2_all + off * e->ld2 : nullptr)))
         return rc;
@@ -441,7 +446,7 @@ using namespace cc;
 
 extern "C" {
 
-int cc_version(void) { return 101; }   // 101: cc_comm_*, cc_knn_l2_sharded, float64 prefilter hooks
+int cc_version(void) { return 102; }   // 102: cc_shutdown, kNN workspace handles (cc_knn_create / cc_knn_search_dev), GPU-side CSR check
 const char *cc_last_error(void) { return g_err.c_str(); }
 
 int cc_device_count(void) {
@@ -454,6 +459,13 @@ int cc_init(int device) {
   int n = 0;
   CC_HIP(hipGetDeviceCount(&n));
   CC_REQUIRE(device >= 0 && device < n, "device %d not available (%d HIP devices visible)", device, n);
+  if (g_stream) {
+    if (g_device == device) return CC_OK;
+    // handles, packed weights and scratch live on the first device: switching under them would launch on one
+    // device with pointers of the other
+    set_error("cc_init(%d): the library is initialised on device %d; call cc_shutdown() first", device, g_device);
+    return CC_ESTATE;
+  }
   CC_HIP(hipSetDevice(device));
   hipDeviceProp_t prop;
   CC_HIP(hipGetDeviceProperties(&prop, device));
@@ -461,13 +473,31 @@ int cc_init(int device) {
     set_error("device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
     return CC_EHIP;
   }
-  if (g_stream && g_device == device) return CC_OK;
-  if (g_stream) { (void)hipStreamDestroy(g_stream); g_stream = nullptr; }
-  if (g_stream2) { (void)hipStreamDestroy(g_stream2); g_stream2 = nullptr; }
-  g_cur = nullptr;
   CC_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
   CC_HIP(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
+  g_cur = nullptr;
   g_device = device;
+  return CC_OK;
+}
+
+int cc_shutdown(void) {
+  if (!g_stream) return CC_OK;
+  (void)hipStreamSynchronize(g_stream);
+  if (g_stream2) (void)hipStreamSynchronize(g_stream2);
+  prof_drain();
+  g_prof_on = false;
+  for (hipEvent_t ev : g_event_pool) (void)hipEventDestroy(ev);
+  g_event_pool.clear();
+  hipEvent_t *evs[] = {&g_lead_done, &g_slot_free[0], &g_slot_free[1], &g_slot_full[0], &g_slot_full[1]};
+  for (hipEvent_t *ev : evs) {
+    if (*ev) (void)hipEventDestroy(*ev);
+    *ev = nullptr;
+  }
+  knn_default_ws_release();
+  (void)hipStreamDestroy(g_stream);
+  if (g_stream2) (void)hipStreamDestroy(g_stream2);
+  g_stream = g_stream2 = g_cur = nullptr;
+  g_device = -1;
   return CC_OK;
 }
 
@@ -547,14 +577,6 @@ int cc_csr_upload(const int64_t *indptr, const int32_t *indices, const float *va
   CC_REQUIRE(initialised(), "cc_init has not been called");
   CC_REQUIRE(csr && indptr && n_rows >= 0 && nnz >= 0 && G >= 1, "bad CSR arguments");
   CC_REQUIRE(indptr[0] == 0 && indptr[n_rows] == nnz, "indptr must start at 0 and end at nnz");
-  for (int64_t r = 0; r < n_rows; ++r) {
-    CC_REQUIRE(indptr[r] <= indptr[r + 1], "indptr not monotone at row %lld", (long long)r);
-    for (int64_t p = indptr[r]; p < indptr[r + 1]; ++p) {
-      CC_REQUIRE(indices[p] >= 0 && indices[p] < G, "column %d at row %lld outside [0,%d)", indices[p], (long long)r, G);
-      CC_REQUIRE(p == indptr[r] || indices[p - 1] < indices[p], "columns of row %lld not strictly increasing",
-                 (long long)r);
-    }
-  }
   Csr *c = new Csr();
   c->n_rows = n_rows; c->nnz = nnz; c->G = G; c->owned = true;
   auto fail = [&](int rc) { cc_csr_free(c); return rc; };
@@ -570,6 +592,8 @@ int cc_csr_upload(const int64_t *indptr, const int32_t *indices, const float *va
     set_error("hipMemcpy failed for CSR upload");
     return fail(CC_EHIP);
   }
+  // canonical form (monotone indptr, columns strictly increasing and < G) is checked where the arrays now are
+  if (int rc = validate_csr(c->indptr, c->indices, n_rows, nnz, G)) return fail(rc);
   if (int rc = csr_build_index(c)) return fail(rc);
   *csr = c;
   return CC_OK;
@@ -584,6 +608,7 @@ int cc_csr_wrap_device(const int64_t *dev_indptr, const int32_t *dev_indices, co
   c->indices = const_cast<int32_t *>(dev_indices);
   c->vals = const_cast<float *>(dev_vals);
   c->n_rows = n_rows; c->nnz = nnz; c->G = G; c->owned = false;
+  if (int rc = validate_csr(c->indptr, c->indices, n_rows, nnz, G)) { cc_csr_free(c); return rc; }
   if (int rc = csr_build_index(c)) { cc_csr_free(c); return rc; }
   *csr = c;
   return CC_OK;
@@ -609,27 +634,23 @@ int cc_gather_dense(void *csr, const int64_t *row_ids, int64_t row_start, int64_
   if ((rc = check_rows(c, row_ids, row_start, n))) return rc;
   CC_REQUIRE(ld >= c->G && ld % 4 == 0, "ld=%lld must be a multiple of 4 and >= G=%d", (long long)ld, c->G);
   if (n == 0) return CC_OK;
-  int64_t *d_ids = nullptr;
+  DevPtr ids_buf, out_buf;   // released on every return path
+  const int64_t *d_ids = nullptr;
   float *d_out = static_cast<float *>(out);
   if (row_ids) {
-    CC_HIP(hipMalloc(&d_ids, sizeof(int64_t) * (size_t)n));
-    CC_HIP(hipMemcpyAsync(d_ids, row_ids, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, stream()));
+    CC_HIP(ids_buf.alloc(sizeof(int64_t) * (size_t)n));
+    CC_HIP(hipMemcpyAsync(ids_buf.p, row_ids, sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, stream()));
+    d_ids = ids_buf.as<int64_t>();
   }
-  if (!out_is_device) CC_HIP(hipMalloc(&d_out, sizeof(float) * (size_t)(n * ld)));
+  if (!out_is_device) {
+    CC_HIP(out_buf.alloc(sizeof(float) * (size_t)(n * ld)));
+    d_out = out_buf.as<float>();
+  }
   const double nnz_hint = c->n_rows ? (double)c->nnz / (double)c->n_rows * (double)n : 0.0;
   rc = launch_gather(c->indptr, c->indices, c->vals, c->chunk_rel, d_ids, row_start, n, c->G, ld, d_out, nnz_hint);
-  if (rc == CC_OK && !out_is_device) {
-    if (hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)(n * ld), hipMemcpyDeviceToHost, stream()) != hipSuccess) {
-      set_error("hipMemcpy D2H failed in cc_gather_dense");
-      rc = CC_EHIP;
-    }
-  }
-  if (hipStreamSynchronize(stream()) != hipSuccess && rc == CC_OK) {
-    set_error("stream synchronise failed in cc_gather_dense: %s", hipGetErrorString(hipGetLastError()));
-    rc = CC_EHIP;
-  }
-  if (d_ids) (void)hipFree(d_ids);
-  if (!out_is_device) (void)hipFree(d_out);
+  if (rc == CC_OK && !out_is_device)
+    CC_HIP(hipMemcpyAsync(out, d_out, sizeof(float) * (size_t)(n * ld), hipMemcpyDeviceToHost, stream()));
+  CC_HIP(hipStreamSynchronize(stream()));   // also when the launch failed: the row-id copy may still be in flight
   return rc;
 }
 
@@ -640,17 +661,19 @@ int cc_encode_dev(void *enc, void *csr, const int64_t *row_ids, int64_t row_star
 int cc_encode(void *enc, void *csr, const int64_t *row_ids, int64_t row_start, int64_t n, float *host_out) {
   Encoder *e = static_cast<Encoder *>(enc);
   if (n <= 0) return encode_csr_dev(e, static_cast<Csr *>(csr), row_ids, row_start, n, nullptr);
-  float *d_out = nullptr;
-  CC_HIP(hipMalloc(&d_out, sizeof(float) * (size_t)(n * e->E)));
-  int rc = encode_csr_dev(e, static_cast<Csr *>(csr), row_ids, row_start, n, d_out);
-  if (rc == CC_OK && hipMemcpy(host_out, d_out, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost) != hipSuccess) {
-    set_error("hipMemcpy D2H failed in cc_encode");
-    rc = CC_EHIP;
-  }
-  (void)hipFree(d_out);
-  return rc;
+  DevPtr out;
+  CC_HIP(out.alloc(sizeof(float) * (size_t)(n * e->E)));
+  if (int rc = encode_csr_dev(e, static_cast<Csr *>(csr), row_ids, row_start, n, out.as<float>())) return rc;
+  CC_HIP(hipMemcpy(host_out, out.p, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost));
+  return CC_OK;
 }
 
+// Dense host rows (what predict() receives for a DataFrame / ndarray: reference src/bigan_basic.py:28-30 with
+// Keras' float32 cast).  Two workspace slots form a pipeline: while the layer stack of pass i runs on the library
+// stream, the rows of pass i+1 cross PCIe on the second stream into the other slot.  Pageable host memory makes
+// the copy itself block the calling thread, which is why the compute of pass i is enqueued BEFORE the copy of
+// pass i+1 is started; with pinned host memory both are asynchronous.  The path is bound by the host link
+// (120 KB per cell at G = 30000 against ~2 us of GPU time per cell), see DESIGN.md §6.
 int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
   Encoder *e = static_cast<Encoder *>(enc);
@@ -659,67 +682,70 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
   if (e->dirty && (rc = encoder_pack(e))) return rc;
   e->fallback_passes = 0;
   if (n == 0) return CC_OK;
-  const int64_t B = n < e->batch ? n : e->batch;
-  if ((rc = encoder_ensure_ws(e, B, 1))) return rc;
-  const int sl = 0;
-  float *d_out = nullptr;
-  CC_HIP(hipMalloc(&d_out, sizeof(float) * (size_t)(n * e->E)));
-  for (int64_t off = 0; off < n && rc == CC_OK; off += B) {
-    const int64_t m = (n - off < B) ? n - off : B;
-    if (hipMemcpy2DAsync(e->x[sl], sizeof(float) * (size_t)e->ldx, host_x + off * e->G, sizeof(float) * (size_t)e->G,
-                         sizeof(float) * (size_t)e->G, (size_t)m, hipMemcpyHostToDevice, stream()) != hipSuccess) {
-      set_error("hipMemcpy2D H2D failed in cc_encode_dense");
-      rc = CC_EHIP;
-      break;
-    }
+  // passes of at most 2048 rows keep the first (un-overlapped) copy short; one pass when everything fits
+  const int64_t B = n < 2048 ? n : (e->batch < 2048 ? e->batch : 2048);
+  const int64_t npass = ceil_div(n, B);
+  const int slots = npass > 1 ? 2 : 1;
+  if ((rc = encoder_ensure_ws(e, B, slots))) return rc;
+  for (int sl = 0; sl < 2; ++sl) {
+    if (!g_slot_free[sl]) CC_HIP(hipEventCreateWithFlags(&g_slot_free[sl], hipEventDisableTiming));
+    if (!g_slot_full[sl]) CC_HIP(hipEventCreateWithFlags(&g_slot_full[sl], hipEventDisableTiming));
+  }
+  DevPtr out;
+  CC_HIP(out.alloc(sizeof(float) * (size_t)(n * e->E)));
+  CC_HIP(hipStreamSynchronize(g_stream));   // workspace memsets
+  struct Drain {   // an early return must not leave copies or kernels running on buffers about to be freed
+    ~Drain() { (void)hipStreamSynchronize(g_stream); (void)hipStreamSynchronize(g_stream2); g_cur = nullptr; }
+  } drain;
+  auto copy_in = [&](int64_t pass) -> int {
+    const int sl = (int)(pass & 1);
+    const int64_t off = pass * B, m = (n - off < B) ? n - off : B;
+    if (pass >= 2) CC_HIP(hipStreamWaitEvent(g_stream2, g_slot_free[sl], 0));   // pass - 2 has left this slot
+    CC_HIP(hipMemcpy2DAsync(e->x[sl], sizeof(float) * (size_t)e->ldx, host_x + off * e->G, sizeof(float) * (size_t)e->G,
+                            sizeof(float) * (size_t)e->G, (size_t)m, hipMemcpyHostToDevice, g_stream2));
+    CC_HIP(hipEventRecord(g_slot_full[sl], g_stream2));
+    return CC_OK;
+  };
+  if ((rc = copy_in(0))) return rc;
+  for (int64_t pass = 0; pass < npass; ++pass) {
+    const int sl = (int)(pass & 1);
+    const int64_t off = pass * B, m = (n - off < B) ? n - off : B;
+    g_cur = g_stream;
+    CC_HIP(hipStreamWaitEvent(g_stream, g_slot_full[sl], 0));
     bool fp32_pass = e->dtype == CC_DTYPE_F32;
     if (!fp32_pass) {
       int flag = 0;
-      if (hipMemsetAsync(e->d_flag[sl], 0, sizeof(int), stream()) != hipSuccess) { set_error("memset failed"); rc = CC_EHIP; break; }
-      rc = launch_convert_f16(e->x[sl], e->ldx, m, e->G, e->xh[sl], e->ldxh, e->d_flag[sl]);
-      if (rc == CC_OK && e->dtype == CC_DTYPE_F16X2) {
-        if (hipMemcpyAsync(&flag, e->d_flag[sl], sizeof(int), hipMemcpyDeviceToHost, stream()) != hipSuccess ||
-            hipStreamSynchronize(stream()) != hipSuccess) { set_error("flag read failed"); rc = CC_EHIP; break; }
-        if (flag) { fp32_pass = true; e->fallback_passes += 1; }
-      }
-      if (rc == CC_OK && !fp32_pass) rc = encoder_forward16(e, sl, m, d_out + off * e->E);
+      CC_HIP(hipMemsetAsync(e->d_flag[sl], 0, sizeof(int), g_stream));
+      if ((rc = launch_convert_f16(e->x[sl], e->ldx, m, e->G, e->xh[sl], e->ldxh, e->d_flag[sl]))) return rc;
+      CC_HIP(hipMemcpyAsync(&flag, e->d_flag[sl], sizeof(int), hipMemcpyDeviceToHost, g_stream));
+      CC_HIP(hipStreamSynchronize(g_stream));
+      if (fp16_pass_needs_fp32(e->dtype, flag)) { fp32_pass = true; e->fallback_passes += 1; }
+      else if ((rc = encoder_forward16(e, sl, m, out.as<float>() + off * e->E))) return rc;
     }
-    if (rc == CC_OK && fp32_pass) rc = encoder_forward(e, sl, m, d_out + off * e->E);
-    // the staging buffer is reused by the next pass
-    if (rc == CC_OK && hipStreamSynchronize(stream()) != hipSuccess) {
-      set_error("stream synchronise failed in cc_encode_dense");
-      rc = CC_EHIP;
-    }
+    if (fp32_pass && (rc = encoder_forward(e, sl, m, out.as<float>() + off * e->E))) return rc;
+    CC_HIP(hipEventRecord(g_slot_free[sl], g_stream));
+    if (pass + 1 < npass && (rc = copy_in(pass + 1))) return rc;   // crosses PCIe underneath the kernels just enqueued
   }
-  if (rc == CC_OK && hipMemcpy(host_out, d_out, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost) != hipSuccess) {
-    set_error("hipMemcpy D2H failed in cc_encode_dense");
-    rc = CC_EHIP;
-  }
-  (void)hipFree(d_out);
-  return rc;
+  CC_HIP(hipStreamSynchronize(g_stream));
+  CC_HIP(hipMemcpy(host_out, out.p, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost));
+  return CC_OK;
 }
 
 // ---- kNN -------------------------------------------------------------------------------
 int cc_knn_l2_dev(const float *dev_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q, int k,
                   int include_self, int32_t *host_idx, float *host_dist) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
-  return knn_run(dev_x, n_total, d, q_begin, n_q, k, include_self, host_idx, host_dist);
+  return knn_run(nullptr, dev_x, n_total, d, q_begin, n_q, k, include_self, host_idx, host_dist);
 }
 
 int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_self, int32_t *host_idx,
               float *host_dist) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
   CC_REQUIRE(n_total > 0 && d > 0, "knn: empty input");
-  float *d_x = nullptr;
-  CC_HIP(hipMalloc(&d_x, sizeof(float) * (size_t)(n_total * d)));
-  int rc = CC_OK;
-  if (hipMemcpy(d_x, host_x, sizeof(float) * (size_t)(n_total * d), hipMemcpyHostToDevice) != hipSuccess) {
-    set_error("hipMemcpy H2D failed in cc_knn_l2");
-    rc = CC_EHIP;
-  }
-  if (rc == CC_OK) rc = knn_run(d_x, n_total, d, 0, n_total, k, include_self, host_idx, host_dist);
-  (void)hipFree(d_x);
-  return rc;
+  DevPtr x;
+  CC_HIP(x.alloc(sizeof(float) * (size_t)(n_total * d)));
+  CC_HIP(hipMemcpy(x.p, host_x, sizeof(float) * (size_t)(n_total * d), hipMemcpyHostToDevice));
+  return knn_run(nullptr, x.as<float>(), n_total, d, 0, n_total, k, include_self, host_idx, host_dist);
 }
 
 // ---- profiling ----------------------------------------------------------------------------

@@ -168,7 +168,7 @@ int cc_knn_l2_sharded(void *comm, const float *dev_local_x, int64_t n_local, int
   }
   CC_RCCL(g_rccl.all_gather(send, c->d_all, (size_t)per * (size_t)d, kNcclFloat, c->nccl, cc::stream()));
   // blocks are back to back for the first n_total rows (only the last non-empty block is short)
-  return cc::knn_run(c->d_all, n_total, d, lo, n_local, k, include_self, host_idx, host_dist);
+  return cc::knn_run(nullptr, c->d_all, n_total, d, lo, n_local, k, include_self, host_idx, host_dist);
 }
 
 }  // extern "C"

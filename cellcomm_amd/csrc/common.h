@@ -44,6 +44,37 @@ struct ProfScope {
     }                                                                             \
   } while (0)
 
+// Device allocation released when it goes out of scope (temporaries of one call: no leak on an early return).
+struct DevPtr {
+  void *p = nullptr;
+  DevPtr() = default;
+  DevPtr(const DevPtr &) = delete;
+  DevPtr &operator=(const DevPtr &) = delete;
+  ~DevPtr() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <class T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+// Grow-only device scratch owned by a handle and kept across calls; release() on the owner's free.
+struct DevBuf {
+  void *p = nullptr;
+  size_t cap = 0;
+  int alloc(size_t bytes) {
+    if (bytes <= cap && p) return CC_OK;
+    release();
+    bytes = bytes ? bytes : 16;
+    CC_HIP(hipMalloc(&p, bytes));
+    cap = bytes;
+    return CC_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  template <class T> T *as() { return reinterpret_cast<T *>(p); }
+};
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
 
@@ -79,7 +110,6 @@ void free_weight(PackedWeight *w);
 // lda* must cover KT*·BK columns and the columns beyond K* must be zero.
 int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M,
                 const PackedWeight &W, float *C, int64_t ldc, int act, int prof_class);
-extern bool g_gemm_pace;   // workgroup pacing of layers 1-2 (gemm.hip); only while one GEMM runs at a time
 int launch_row_softmax(float *X, int64_t M, int E, int64_t ld);
 
 // gemm16.hip — layers 1/2 on the fp16 matrix cores (CC_DTYPE_F16 / CC_DTYPE_F16X2)
@@ -105,8 +135,15 @@ int launch_gather_f16(const int64_t *d_indptr, const int32_t *d_indices, const f
                       const int32_t *d_chunk_rel, const int64_t *d_row_ids, int64_t row_start, int64_t n, int G,
                       int64_t ld, void *d_out_half, int *d_inexact, double nnz_hint);
 
-// knn.hip
-int knn_run(const float *d_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q, int k,
+// gather.hip — canonical-form check of device-resident CSR arrays (cc_csr_upload / cc_csr_wrap_device):
+// indptr monotone from 0 to nnz, columns of a row strictly increasing and inside [0, G)
+int validate_csr(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, int64_t nnz, int G);
+
+// knn.hip — ws == nullptr: the library's default workspace (released by cc_shutdown)
+struct KnnWorkspace;
+KnnWorkspace *knn_default_ws();
+void knn_default_ws_release();
+int knn_run(KnnWorkspace *ws, const float *d_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q, int k,
             int include_self, int32_t *h_idx, float *h_dist);
 
 }  // namespace cc

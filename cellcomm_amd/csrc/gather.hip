@@ -78,8 +78,19 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_kernel(
   for (int i = tid; i < n4; i += GATHER_THREADS) orow[i] = tile4[i];
 }
 
+__device__ __forceinline__ int fp16_flags(float v) {
+  const float back = (float)(_Float16)v;
+  return (back != v ? 1 : 0) | ((isinf(back) && !isinf(v)) || isnan(v) ? 2 : 0);
+}
+__device__ __forceinline__ void raise_fp16_flags(int bad, int *flags) {
+  const int any1 = __any(bad & 1), any2 = __any(bad & 2);
+  if ((any1 | any2) && (threadIdx.x & 63) == 0) atomicOr(flags, (any1 ? 1 : 0) | (any2 ? 2 : 0));
+}
+
 // fp16 output variant (CC_DTYPE_F16 / F16X2 encoders): same staging, the tile leaves as 8 halfs per
-// lane; *inexact is raised when a value does not survive the round trip through fp16.
+// lane; *inexact gets bit 0 when a value does not survive the round trip through fp16 and bit 1 when a
+// finite value leaves the fp16 range (|v| > 65504 becomes inf: such a pass must run on the fp32 kernels
+// in BOTH fp16 modes — inf·0 in the MFMA would turn the row into NaN).
 __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_f16_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ vals, const int32_t *__restrict__ chunk_rel, int nc1,
@@ -102,13 +113,13 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_f16_kernel(
 #pragma unroll
   for (int i = tid; i < GATHER_CH / 4; i += GATHER_THREADS) tile4[i] = z;
   __syncthreads();
-  bool bad = false;
+  int bad = 0;
   for (int64_t p = lo + tid; p < hi; p += GATHER_THREADS) {
     const float v = vals[p];
-    bad |= (float)(_Float16)v != v;
+    bad |= fp16_flags(v);
     tile[indices[p] - (int32_t)c0] = v;
   }
-  if (__any(bad) && (tid & 63) == 0) atomicOr(inexact, 1);
+  raise_fp16_flags(bad, inexact);
   __syncthreads();
 
   using h8v = __attribute__((ext_vector_type(8))) _Float16;
@@ -121,6 +132,50 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_f16_kernel(
     o[4] = (_Float16)b.x; o[5] = (_Float16)b.y; o[6] = (_Float16)b.z; o[7] = (_Float16)b.w;
     orow[i] = o;
   }
+}
+
+// ---- canonical-form check (replaces a serial host loop over every non-zero) -----------------------
+// err[0] = smallest offending row + 1 (0 = clean), err[1] = what was wrong there
+__global__ __launch_bounds__(256) void csr_validate_kernel(const int64_t *__restrict__ indptr,
+                                                           const int32_t *__restrict__ indices, int64_t n_rows,
+                                                           int64_t nnz, int G, unsigned long long *__restrict__ err) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per row
+  if (row >= n_rows) return;
+  const int64_t lo = indptr[row], hi = indptr[row + 1];
+  int bad = 0;
+  if (lo > hi || lo < 0 || hi > nnz) {
+    bad = 1;
+  } else {
+    for (int64_t p = lo + lane; p < hi; p += 64) {
+      const int32_t c = indices[p];
+      if (c < 0 || c >= G) bad = 2;
+      else if (p > lo && indices[p - 1] >= c) bad = bad ? bad : 3;
+    }
+  }
+  const int code = __any(bad == 1) ? 1 : __any(bad == 2) ? 2 : __any(bad == 3) ? 3 : 0;
+  if (code && lane == 0) atomicMin(err, ((unsigned long long)(row + 1) << 2) | (unsigned)code);
+}
+
+int validate_csr(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, int64_t nnz, int G) {
+  if (n_rows == 0) return CC_OK;
+  DevPtr err;
+  CC_HIP(err.alloc(sizeof(unsigned long long)));
+  CC_HIP(hipMemsetAsync(err.p, 0xff, sizeof(unsigned long long), stream()));
+  hipLaunchKernelGGL(csr_validate_kernel, dim3((unsigned)ceil_div(n_rows, 4)), dim3(256), 0, stream(), d_indptr,
+                     d_indices, n_rows, nnz, G, err.as<unsigned long long>());
+  CC_HIP(hipGetLastError());
+  unsigned long long h = 0;
+  CC_HIP(hipMemcpyAsync(&h, err.p, sizeof h, hipMemcpyDeviceToHost, stream()));
+  CC_HIP(hipStreamSynchronize(stream()));
+  if (h == ~0ull) return CC_OK;
+  const long long row = (long long)(h >> 2) - 1;
+  switch ((int)(h & 3)) {
+    case 1: CC_REQUIRE(false, "indptr not monotone inside [0, nnz] at row %lld", row);
+    case 2: CC_REQUIRE(false, "a column of row %lld is outside [0,%d)", row, G);
+    default: CC_REQUIRE(false, "columns of row %lld not strictly increasing", row);
+  }
+  return CC_OK;
 }
 
 int gather_chunk_count(int G) { return (int)ceil_div(G, GATHER_CH) + 1; }
@@ -157,16 +212,15 @@ int launch_gather(const int64_t *d_indptr, const int32_t *d_indices, const float
 __global__ void convert_f32_f16_kernel(const float *__restrict__ x, int64_t ldx, int64_t M, int G,
                                        _Float16 *__restrict__ out, int64_t ldo, int *__restrict__ inexact) {
   const int64_t total = M * G;
-  bool bad = false;
+  int bad = 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
     const int64_t row = t / G;
     const int col = (int)(t % G);
     const float v = x[row * ldx + col];
-    const _Float16 hv = (_Float16)v;
-    bad |= (float)hv != v;
-    out[row * ldo + col] = hv;
+    bad |= fp16_flags(v);
+    out[row * ldo + col] = (_Float16)v;
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(inexact, 1);
+  raise_fp16_flags(bad, inexact);
 }
 
 int launch_convert_f16(const float *d_x, int64_t ldx, int64_t M, int G, void *d_out_half, int64_t ldo, int *d_inexact) {

@@ -31,8 +31,6 @@
 //     error of stage 1: every point outside the list is then provably farther.
 //  3. fallback — uncertified queries (dense duplicates / near ties) are rescanned
 //     against all candidates in float64, bounded by their stage-2 k-th key.
-#include <cstdlib>
-
 #include "common.h"
 
 namespace cc {
@@ -41,16 +39,9 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;  // native vector: arrays of it stay in VGPRs
 using u64 = unsigned long long;
 
-static bool g_force_fallback = false;
-static bool g_force_route_a = false;  // test hook: always take the full-select route
 #ifndef CC_KNN_SELECT16
 #define CC_KNN_SELECT16 1
 #endif
-static bool g_use_fp16_select = CC_KNN_SELECT16 != 0;   // sample pass of stage 1b on the fp16 matrix cores too
-static bool g_use_fp16_collect = true; // stage 1b collect on the fp16 matrix cores when the data's scale allows
-static bool g_use_fp64_prefilter = true; // stage 3: float64 matrix-core prefilter in front of the exact scan
-static int64_t g_last_fallback = 0;
-static int64_t g_last_full_scan = 0;     // fallback queries that had to scan every candidate in float64 VALU
 
 __device__ __forceinline__ unsigned f32_to_ordered(float f) {
   unsigned b = __float_as_uint(f);
@@ -1293,21 +1284,39 @@ __global__ __launch_bounds__(64) void knn_prefilter64_kernel(
 }
 
 // ---- host orchestration ----------------------------------------------------------------------
-// Grow-only device scratch kept across calls (hipMalloc/hipFree per call cost ~10 ms of the
-// 100k-cell step).  Never freed: the process owns one set.
-struct DevBuf {
-  void *p = nullptr;
-  size_t cap = 0;
-  int alloc(size_t bytes) {
-    if (bytes <= cap && p) return CC_OK;
-    if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
-    bytes = bytes ? bytes : 16;
-    CC_HIP(hipMalloc(&p, bytes));
-    cap = bytes;
-    return CC_OK;
+// All state of a search lives in a workspace handle: grow-only device scratch kept across calls
+// (hipMalloc/hipFree per call cost ~10 ms of the 100k-cell step), the route options and the statistics of
+// the last call.  cc_knn_create / cc_knn_free own one; the convenience entry points (cc_knn_l2, cc_knn_l2_dev,
+// cc_knn_l2_sharded) use the library's default workspace, which cc_shutdown releases.
+struct KnnWorkspace {
+  DevBuf P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
+      bnd_d, bnd_i, partial, mu, norm64, max64, plist, pcnt, nfull;
+  bool force_fallback = false;             // test hook: every query through the float64 stage
+  bool force_route_a = false;              // test hook: always take the full-select route
+  bool use_fp16_select = CC_KNN_SELECT16 != 0;   // sample pass of stage 1b on the fp16 matrix cores too
+  bool use_fp16_collect = true;            // stage 1b collect on the fp16 matrix cores when the data's scale allows
+  bool use_fp64_prefilter = true;          // stage 3: float64 matrix-core prefilter in front of the exact scan
+  int collect_splits = 0;                  // 0 = chosen per call; > 0 = forced (tools/knn_split_sweep.sh)
+  int64_t last_fallback = 0;
+  int64_t last_full_scan = 0;              // fallback queries that had to scan every candidate in float64 VALU
+  void release() {
+    DevBuf *all[] = {&P, &P16, &norms, &maxn, &keys, &cnts, &bound, &skeys, &scnts, &Tq, &cbuf, &ccur, &oidx, &odist,
+                     &nflag, &flagged, &bnd_d, &bnd_i, &partial, &mu, &norm64, &max64, &plist, &pcnt, &nfull};
+    for (DevBuf *b : all) b->release();
   }
-  template <class T> T *as() { return reinterpret_cast<T *>(p); }
 };
+
+static KnnWorkspace *g_default_ws = nullptr;
+KnnWorkspace *knn_default_ws() {
+  if (!g_default_ws) g_default_ws = new KnnWorkspace();
+  return g_default_ws;
+}
+void knn_default_ws_release() {
+  if (!g_default_ws) return;
+  g_default_ws->release();
+  delete g_default_ws;
+  g_default_ws = nullptr;
+}
 
 struct SelectArgs {
   const float4 *P; const float *norms, *x, *mu;
@@ -1408,9 +1417,11 @@ static void make_splits(int64_t NB, int want, int *S, int64_t *NBs) {
   *NBs = nbs;
 }
 
-int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, int k, int include_self,
-            int32_t *h_idx, float *h_dist) {
-  g_last_fallback = 0;
+int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, int k,
+            int include_self, int32_t *h_idx, float *h_dist) {
+  KnnWorkspace &ws = wsp ? *wsp : *knn_default_ws();
+  ws.last_fallback = 0;
+  ws.last_full_scan = 0;
   CC_REQUIRE(N > 0 && N < (int64_t)2147483000, "knn: n_total=%lld out of range", (long long)N);
   CC_REQUIRE(d >= 1 && d <= 132, "knn: d=%d unsupported (1..132)", d);
   CC_REQUIRE(k >= 1 && k <= 128, "knn: k=%d unsupported (1..128)", k);
@@ -1457,12 +1468,14 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
 #ifndef CC_KNN_SAMPLED_MAXK
 #define CC_KNN_SAMPLED_MAXK 128
 #endif
-  const bool collect_all = !g_force_route_a && k <= CC_KNN_SAMPLED_MAXK && N <= col_cap;
-  const bool sampled = collect_all || (!g_force_route_a && NB >= CC_KNN_MIN_SBLK * SAMPLE &&
+  const bool collect_all = !ws.force_route_a && k <= CC_KNN_SAMPLED_MAXK && N <= col_cap;
+  const bool sampled = collect_all || (!ws.force_route_a && NB >= CC_KNN_MIN_SBLK * SAMPLE &&
                                        N >= (int64_t)CC_KNN_MIN_SBLK * SAMPLE * m && k <= CC_KNN_SAMPLED_MAXK);
 
-  static DevBuf P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
-      bnd_d, bnd_i, partial, mu;
+  DevBuf &P = ws.P, &P16 = ws.P16, &norms = ws.norms, &maxn = ws.maxn, &keys = ws.keys, &cnts = ws.cnts,
+         &bound = ws.bound, &skeys = ws.skeys, &scnts = ws.scnts, &Tq = ws.Tq, &cbuf = ws.cbuf, &ccur = ws.ccur,
+         &oidx = ws.oidx, &odist = ws.odist, &nflag = ws.nflag, &flagged = ws.flagged, &bnd_d = ws.bnd_d,
+         &bnd_i = ws.bnd_i, &partial = ws.partial, &mu = ws.mu;
   int rc;
   if ((rc = norms.alloc(sizeof(float) * (size_t)N))) return rc;
   if ((rc = maxn.alloc(16))) return rc;
@@ -1543,7 +1556,7 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
       for (int o : {1, 2, 4, 8})
         if (16 * o >= d) { ND16 = o; break; }
       float scale16 = 0.f;
-      if (g_use_fp16_collect && ND16) {
+      if (ws.use_fp16_collect && ND16) {
         unsigned h_max[2] = {0, 0};
         CC_HIP(hipMemcpyAsync(h_max, maxn.p, sizeof h_max, hipMemcpyDeviceToHost, stream()));
         CC_HIP(hipStreamSynchronize(stream()));
@@ -1567,7 +1580,7 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
       } else {
         if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS) * (size_t)SS))) return rc;
         if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q * (size_t)SS))) return rc;
-        if (scale16 > 0.f && g_use_fp16_select && ND16 <= 4) {   // ND = 8 (d > 64) spills: fp32 select there
+        if (scale16 > 0.f && ws.use_fp16_select && ND16 <= 4) {   // ND = 8 (d > 64) spills: fp32 select there
           if ((rc = run_select16(ND16, P16.as<h8>(), sa, scale16, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(),
                                  scnts.as<int>())))
             return rc;
@@ -1582,10 +1595,10 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
       // 8 splits = one per XCD (its slice of the panels stays in that XCD's L2).  Workgroups all take the same
       // time, so what counts is whole rounds over the 768 resident slots (3 per CU): when 8 splits spill a few
       // workgroups into an extra round (a 12.5k-query shard: 784), fewer, longer splits that fit the rounds win
-      // even though they lose the XCD affinity (measured: CC_KNN_COLLECT_SPLITS override, tools/knn_sweep.sh).
+      // even though they lose the XCD affinity (measured with the CC_KNN_OPT_COLLECT_SPLITS override, tools/knn_split_sweep.sh).
       {
         int want = 8;
-        static const int forced = std::getenv("CC_KNN_COLLECT_SPLITS") ? atoi(std::getenv("CC_KNN_COLLECT_SPLITS")) : 0;
+        const int forced = ws.collect_splits;
         if (forced > 0) {
           want = forced;
         } else {
@@ -1646,24 +1659,24 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
     ProfScope prof(CC_PROF_KNN_RERANK, 3.0 * (double)n_q * (double)KP * (double)d);
     hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), per_wave * 4, stream(), d_x,
                        norms.as<float>(), maxn.as<unsigned>(), d, q_begin, n_q, keys.as<u64>(), cnts.as<int>(),
-                       bound.as<float>(), KP, k, eps_coef, g_force_fallback ? 1 : 0, oidx.as<int32_t>(),
+                       bound.as<float>(), KP, k, eps_coef, ws.force_fallback ? 1 : 0, oidx.as<int32_t>(),
                        odist.as<float>(), nflag.as<int>(), flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>());
     CC_HIP(hipGetLastError());
   }
   int h_nflag = 0;
   CC_HIP(hipMemcpyAsync(&h_nflag, nflag.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
   CC_HIP(hipStreamSynchronize(stream()));
-  g_last_fallback = h_nflag;
-  g_last_full_scan = 0;
+  ws.last_fallback = h_nflag;
+  ws.last_full_scan = 0;
   if (h_nflag > 0) {
     const size_t lds = sizeof(double) * (size_t)(FB_CAP + d + 1) + sizeof(int) * (size_t)(FB_CAP + 2);
     ProfScope prof(CC_PROF_KNN_FALLBACK, 3.0 * (double)h_nflag * (double)N * (double)d);
     const int *d_list = nullptr, *d_list_cnt = nullptr;
     const int list_cap = 4096;
-    static DevBuf norm64, max64, plist, pcnt, nfull;
+    DevBuf &norm64 = ws.norm64, &max64 = ws.max64, &plist = ws.plist, &pcnt = ws.pcnt, &nfull = ws.nfull;
     if ((rc = nfull.alloc(16))) return rc;
     CC_HIP(hipMemsetAsync(nfull.p, 0, 16, stream()));
-    if (g_use_fp64_prefilter && N >= 2048) {
+    if (ws.use_fp64_prefilter && N >= 2048) {
       // 3a: float64 matrix-core prefilter, 16 flagged queries per wave
       int ND64 = 0;
       for (int o : {1, 2, 4, 9})
@@ -1709,7 +1722,7 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
     int h_full = 0;
     CC_HIP(hipMemcpyAsync(&h_full, nfull.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
     CC_HIP(hipStreamSynchronize(stream()));
-    g_last_full_scan = h_full;
+    ws.last_full_scan = h_full;
   }
   CC_HIP(hipMemcpyAsync(h_idx, oidx.p, sizeof(int32_t) * (size_t)(n_q * k), hipMemcpyDeviceToHost, stream()));
   CC_HIP(hipMemcpyAsync(h_dist, odist.p, sizeof(float) * (size_t)(n_q * k), hipMemcpyDeviceToHost, stream()));
@@ -1719,21 +1732,62 @@ int knn_run(const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, in
 
 }  // namespace cc
 
-extern "C" int cc_knn_force_fallback(int on) {
-  cc::g_force_fallback = on != 0;
+extern "C" {
+
+int cc_knn_create(void **knn) {
+  CC_REQUIRE(knn != nullptr, "knn is NULL");
+  *knn = new cc::KnnWorkspace();
   return CC_OK;
 }
-extern "C" int64_t cc_knn_last_fallback_count(void) { return cc::g_last_fallback; }
-extern "C" int64_t cc_knn_last_full_scan_count(void) { return cc::g_last_full_scan; }
-extern "C" int cc_knn_use_fp64_prefilter(int on) {
-  cc::g_use_fp64_prefilter = on != 0;
+
+void cc_knn_free(void *knn) {
+  if (!knn) return;
+  cc::KnnWorkspace *ws = static_cast<cc::KnnWorkspace *>(knn);
+  ws->release();
+  delete ws;
+}
+
+int cc_knn_set_option(void *knn, int option, int value) {
+  cc::KnnWorkspace *ws = knn ? static_cast<cc::KnnWorkspace *>(knn) : cc::knn_default_ws();
+  switch (option) {
+    case CC_KNN_OPT_FORCE_FALLBACK: ws->force_fallback = value != 0; break;
+    case CC_KNN_OPT_FORCE_FULL_SELECT: ws->force_route_a = value != 0; break;
+    case CC_KNN_OPT_FP16_COLLECT: ws->use_fp16_collect = value != 0; break;
+    case CC_KNN_OPT_FP16_SELECT: ws->use_fp16_select = value != 0; break;
+    case CC_KNN_OPT_FP64_PREFILTER: ws->use_fp64_prefilter = value != 0; break;
+    case CC_KNN_OPT_COLLECT_SPLITS:
+      CC_REQUIRE(value >= 0 && value <= 64, "collect splits %d outside [0, 64]", value);
+      ws->collect_splits = value;
+      break;
+    default: CC_REQUIRE(false, "unknown kNN option %d", option);
+  }
   return CC_OK;
 }
-extern "C" int cc_knn_use_fp16_collect(int on) {
-  cc::g_use_fp16_collect = on != 0;
+
+int cc_knn_stat(void *knn, int stat, int64_t *value) {
+  CC_REQUIRE(value != nullptr, "value is NULL");
+  cc::KnnWorkspace *ws = knn ? static_cast<cc::KnnWorkspace *>(knn) : cc::knn_default_ws();
+  switch (stat) {
+    case CC_KNN_STAT_FALLBACK_QUERIES: *value = ws->last_fallback; break;
+    case CC_KNN_STAT_FULL_SCAN_QUERIES: *value = ws->last_full_scan; break;
+    default: CC_REQUIRE(false, "unknown kNN statistic %d", stat);
+  }
   return CC_OK;
 }
-extern "C" int cc_knn_force_full_select(int on) {
-  cc::g_force_route_a = on != 0;
-  return CC_OK;
+
+int cc_knn_search_dev(void *knn, const float *dev_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q, int k,
+                      int include_self, int32_t *host_idx, float *host_dist) {
+  CC_REQUIRE(cc::initialised(), "cc_init has not been called");
+  return cc::knn_run(static_cast<cc::KnnWorkspace *>(knn), dev_x, n_total, d, q_begin, n_q, k, include_self, host_idx,
+                     host_dist);
 }
+
+// the hooks of ABI v101, kept as shorthands for options of the default workspace
+int cc_knn_force_fallback(int on) { return cc_knn_set_option(nullptr, CC_KNN_OPT_FORCE_FALLBACK, on); }
+int cc_knn_use_fp64_prefilter(int on) { return cc_knn_set_option(nullptr, CC_KNN_OPT_FP64_PREFILTER, on); }
+int cc_knn_use_fp16_collect(int on) { return cc_knn_set_option(nullptr, CC_KNN_OPT_FP16_COLLECT, on); }
+int cc_knn_force_full_select(int on) { return cc_knn_set_option(nullptr, CC_KNN_OPT_FORCE_FULL_SELECT, on); }
+int64_t cc_knn_last_fallback_count(void) { return cc::knn_default_ws()->last_fallback; }
+int64_t cc_knn_last_full_scan_count(void) { return cc::knn_default_ws()->last_full_scan; }
+
+}  // extern "C"

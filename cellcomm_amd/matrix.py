@@ -63,8 +63,16 @@ class CellMatrix:
     def sample(self, n, random_state=None):
         """Rows drawn without replacement, like DataFrame.sample (reference
         src/cell_type_training.py:37-38): positions are
-        RandomState(seed).choice(len, n, replace=False), exactly what pandas does."""
-        rs = random_state if isinstance(random_state, np.random.RandomState) else np.random.RandomState(random_state)
+        RandomState(seed).choice(len, n, replace=False), exactly what pandas does.  With
+        random_state=None pandas draws from NumPy's GLOBAL state (pandas.core.common.random_state
+        returns np.random for None), so a caller's np.random.seed(...) reproduces the batches of
+        CellTraining.run() here exactly as it does with the reference."""
+        if random_state is None:
+            rs = np.random.mtrand._rand
+        elif isinstance(random_state, np.random.RandomState):
+            rs = random_state
+        else:
+            rs = np.random.RandomState(random_state)
         locs = rs.choice(self.shape[0], size=n, replace=False)
         return self.take(locs)
 

@@ -17,8 +17,12 @@
  *     (e.g. torch.Tensor.data_ptr()); whatever produced their contents on another
  *     stream must have completed before the call (the library only orders its own work).
  *   - handles are opaque; free them with the matching *_free.
- *   - calls on one handle are not re-entrant; all work is issued on the
- *     library's own HIP stream and every call returns synchronised.
+ *   - ONE device and ONE host thread at a time per process: cc_init binds the library to a
+ *     device and owns its two HIP streams; every call returns synchronised; calls are not
+ *     re-entrant (the reference's callers are single-threaded Python,
+ *     reference src/intercepts/db_recorder.py:82-108).  All device state hangs off handles
+ *     (encoder, generator, CSR, kNN workspace, communicator) or off the library context that
+ *     cc_shutdown releases; after cc_shutdown another device may be chosen with cc_init.
  *   - there is NO CPU fallback anywhere in this library.
  */
 #ifndef CELLCOMM_HIP_H
@@ -45,9 +49,15 @@ extern "C" {
 
 /* ---- runtime ----------------------------------------------------------- */
 
-/* Select the HIP device used by this process and create the library stream.
- * Fails (CC_EHIP) when no gfx950 device is visible. */
+/* Select the HIP device used by this process and create the library streams.
+ * Fails with CC_EHIP when no gfx950 device is visible, with CC_ESTATE when the library is already
+ * initialised on a DIFFERENT device (handles and scratch live there; call cc_shutdown first).
+ * Re-initialising on the same device is a no-op. */
 int cc_init(int device);
+/* Release everything the library context owns: the streams, pooled events, the default kNN workspace.
+ * Handles created by the caller must have been freed before (their device memory belongs to them).
+ * No-op when not initialised. */
+int cc_shutdown(void);
 int cc_version(void);
 const char *cc_last_error(void);
 /* Number of visible HIP devices (0 on a CPU-only host); never fails. */
@@ -72,8 +82,9 @@ int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols);
 int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols);
 /* Rows processed per pass through the layer stack (default 8192 for CC_DTYPE_F32, 16384 for the fp16 dtypes). */
 int cc_encoder_set_batch(void *enc, int64_t batch_rows);
-/* CC_DTYPE_F16X2 only: passes of the last cc_encode* call whose input was not exactly
- * representable in fp16 and therefore ran on the fp32 kernels instead. */
+/* fp16 dtypes: passes of the last cc_encode* call that ran on the fp32 kernels instead — CC_DTYPE_F16X2:
+ * some value of the pass is not exactly an fp16 number; CC_DTYPE_F16: some value lies outside the fp16
+ * range (|v| > 65504 would become inf and turn the row into NaN). */
 int64_t cc_encoder_fp32_fallback_passes(void *enc);
 
 /* ---- generator: replaces keras Model.predict behind BasicBiGan.generate_cells
@@ -94,11 +105,12 @@ int cc_generate_dense(void *gen, const float *host_in, int64_t n, float *host_ou
  *      load_matrix (reference src/cell_type_training.py:9-17) ------------- */
 
 /* indptr[n_rows+1] int64, indices[nnz] int32 (sorted, unique within a row,
- * < G), vals[nnz] float32.  Copies to the device. */
+ * < G), vals[nnz] float32.  Copies to the device and checks the canonical form there (one
+ * kernel pass; CC_EINVAL names the first offending row). */
 int cc_csr_upload(const int64_t *indptr, const int32_t *indices, const float *vals,
                   int64_t n_rows, int64_t nnz, int G, void **csr);
-/* Adopt device-resident CSR arrays (not copied, not freed by cc_csr_free).  The caller guarantees
- * the same canonical form cc_csr_upload checks (columns strictly increasing per row, < G). */
+/* Adopt device-resident CSR arrays (not copied, not freed by cc_csr_free); the same canonical
+ * form is checked (indptr monotone from 0 to nnz, columns strictly increasing per row, < G). */
 int cc_csr_wrap_device(const int64_t *dev_indptr, const int32_t *dev_indices, const float *dev_vals,
                        int64_t n_rows, int64_t nnz, int G, void **csr);
 void cc_csr_free(void *csr);
@@ -142,12 +154,33 @@ void cc_mtx_free(void *mtx);
  * sequential sum of squared float64 differences, returned rounded to float32.
  * include_self = 0 drops candidate j == query index.  idx holds GLOBAL row
  * indices (int32).  Requires k <= n_total - (include_self ? 0 : 1); supported 1 <= k <= 128,
- * 1 <= d <= 132, n_total < 2^31.  Scratch buffers are kept per process on the device chosen by
- * cc_init (one process per GPU). */
+ * 1 <= d <= 132, n_total < 2^31.  cc_knn_l2 / cc_knn_l2_dev / cc_knn_l2_sharded use the library's
+ * default workspace (grow-only scratch, released by cc_shutdown). */
 int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_self,
               int32_t *host_idx, float *host_dist);
 int cc_knn_l2_dev(const float *dev_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q,
                   int k, int include_self, int32_t *host_idx, float *host_dist);
+
+/* A search workspace as a handle of its own: device scratch (grown on demand, kept across calls),
+ * route options and the statistics of the last search.  knn == NULL in the calls below means the
+ * default workspace. */
+int cc_knn_create(void **knn);
+void cc_knn_free(void *knn);
+int cc_knn_search_dev(void *knn, const float *dev_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q,
+                      int k, int include_self, int32_t *host_idx, float *host_dist);
+#define CC_KNN_OPT_FORCE_FALLBACK 0    /* test hook: every query through the float64 stage             */
+#define CC_KNN_OPT_FORCE_FULL_SELECT 1 /* test hook: no sampled threshold, full select (route 1a)      */
+#define CC_KNN_OPT_FP16_COLLECT 2      /* collect pass on the fp16 matrix cores (default 1)            */
+#define CC_KNN_OPT_FP16_SELECT 3       /* sample pass on the fp16 matrix cores (default 1)             */
+#define CC_KNN_OPT_FP64_PREFILTER 4    /* float64 matrix-core prefilter in stage 3 (default 1)         */
+#define CC_KNN_OPT_COLLECT_SPLITS 5    /* candidate splits of the collect pass; 0 = chosen per call    */
+/* None of the options changes a result bit (stage 2 certifies or stage 3 recomputes); only speed. */
+int cc_knn_set_option(void *knn, int option, int value);
+#define CC_KNN_STAT_FALLBACK_QUERIES 0  /* queries of the last search that stage 2 could not certify   */
+#define CC_KNN_STAT_FULL_SCAN_QUERIES 1 /* of those, the ones that scanned ALL candidates in float64   */
+int cc_knn_stat(void *knn, int stat, int64_t *value);
+
+/* Shorthands (ABI v101) for options / statistics of the default workspace. */
 /* Test hook: route every query through the float64 fallback scan. */
 int cc_knn_force_fallback(int on);
 /* Stage 1b collect pass on the fp16 matrix cores (default on) or the fp32 ones; results are

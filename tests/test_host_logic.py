@@ -113,6 +113,20 @@ def test_sample_equals_pandas_sample(seed):
     assert np.array_equal(again.to_dense(np.float64), want.to_numpy()[[3, 0]])
 
 
+def test_sample_without_seed_follows_numpy_global_state():
+    """DataFrame.sample(n) with no seed draws from np.random's global state (what CellTraining.run() relies on,
+    reference src/cell_type_training.py:37-38,42): seeding it must reproduce the same rows here."""
+    m = synth.synth_csr(40, 30, density=0.2, seed=5)
+    df = m.to_dataframe()
+    for seed in (3, 11):
+        np.random.seed(seed)
+        want = [df.sample(7).index.to_numpy() for _ in range(3)]
+        np.random.seed(seed)
+        got = [m.sample(7).index for _ in range(3)]
+        for w, g in zip(want, got):
+            assert np.array_equal(g, w)
+
+
 def test_load_cells_roundtrip(tmp_path):
     m = matrix.load_matrix(MTX)
     path = tmp_path / 'cells.csv'

@@ -47,6 +47,25 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 #define CC_GEMM_SETPRIO 1
 #endif
 
+// CC_GEMM_PACE=1 (experiment, off): workgroups that share panels are kept within a few K-steps of each
+// other (chunks of CC_GEMM_PACE_EVERY K-steps, at most CC_GEMM_PACE_LEAD + 1 chunks ahead of the slowest
+// member).  Measured on layer 1 (tools/pace_sweep.sh, tools/pmc_collect.sh): L2 hit rate 29 % -> 62 % (EVERY=8)
+// / 81 % (EVERY=2), L2-miss traffic 33 -> 17.9 / 8.9 GB per launch, but 137.4 -> 134.7 / 128.5 TFLOP/s:
+// the misses are served on-die and are not on the critical path, while lock-step issue is slower.
+#ifndef CC_GEMM_PACE
+#define CC_GEMM_PACE 0
+#endif
+#ifndef CC_GEMM_PACE_EVERY
+#define CC_GEMM_PACE_EVERY 4
+#endif
+#ifndef CC_GEMM_PACE_LEAD
+#define CC_GEMM_PACE_LEAD 2
+#endif
+#ifndef CC_GEMM_PACE_BUDGET
+#define CC_GEMM_PACE_BUDGET 8192      // polls (~0.25 us each) a workgroup may spend waiting, in total
+#endif
+bool g_gemm_pace = false;             // set by the encoder around single-stream calls
+
 constexpr int BM = GEMM_BM, BN = GEMM_BN, BK = GEMM_BK;
 constexpr int LDS_A_STRIDE = BK + 4;            // floats; (BK+4)·r mod 64 distinct for r mod 16
 constexpr int GEMM_THREADS = 256;
@@ -63,6 +82,17 @@ static_assert(BN == 128 && (BK == 32 || BK == 64), "tile shape");
 
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
+#ifdef CC_GEMM_TRACE
+// diagnostic build only (tools/gemm_trace.py): per-workgroup wall-clock stamps of the layer-1 kernel
+__device__ unsigned long long g_gemm_trace[16384 * 4];
+#endif
+
+// State of the (optional) pacing experiment carried through the K loop.
+struct PaceState {
+  int *pace_grp = nullptr;
+  int pace_size = 0, pace_budget = 0, pace_seen = 0, wave_u = 0;
+};
+
 // The K loop of one wave (wave tile = MTV x NTV blocks of 32 x 32; only 2 x 2 is instantiated).
 // Tried and dropped: edge variants that skip the blocks outside the matrix (N = 3000 leaves the second wave
 // column of the last n-tile all padding, 1/48 of layer 1's MFMAs).  A second instantiation of this loop in
@@ -72,7 +102,8 @@ template <int KCLASS, int MTV, int NTV>
 __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA], f32x4 (&rb)[NB], const float *(&pa)[NA],
                                             const f32x4 *&wt, const int (&a_lr)[NA], const float *__restrict__ A2,
                                             int64_t m0, int64_t lda2, int KT1, int KT, float *As, f32x4 *Bs4,
-                                            const float *a_lds, const f32x4 *b_lds, int tid, int a_row, int a_k4) {
+                                            const float *a_lds, const f32x4 *b_lds, int tid, int a_row, int a_k4,
+                                            PaceState &ps, int bid) {
   for (int kt = 0; kt < KT; ++kt) {
     const bool more = kt + 1 < KT;  // wave-uniform
     if (more) {
@@ -112,7 +143,9 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA]
 #if CC_GEMM_SETPRIO
     __builtin_amdgcn_s_setprio(0);
 #endif
+#ifndef CC_GEMM_FAKE_NOSYNC   // probe: no barriers, no LDS refill (results are wrong): the pure MFMA + fragment-read rate
     __syncthreads();
+#endif
     if (more) {
       float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;
 #pragma unroll
@@ -120,7 +153,33 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA]
 #pragma unroll
       for (int p = 0; p < NB; ++p) Bs4[tid + p * GEMM_THREADS] = rb[p];
     }
+#if CC_GEMM_PACE
+    // wave 0 as a whole (wave-uniform control flow, scalar state: nothing per-lane stays live across
+    // the K loop): its 64 lanes' atomic adds are merged into one +64 by the compiler
+    if (ps.pace_grp && ps.wave_u == 0 && (kt + 1) % CC_GEMM_PACE_EVERY == 0) {
+      const int c = (kt + 1) / CC_GEMM_PACE_EVERY - 1;
+      // the counter this boundary depends on was read one boundary ago (ps.pace_seen: a whole chunk for the
+      // load to return), so a group that is in step never waits for memory here; nothing of this wave
+      // is in flight at this point, so consuming ps.pace_seen does not wait for the atomic below either
+      if (c >= CC_GEMM_PACE_LEAD && __builtin_amdgcn_readfirstlane(ps.pace_seen) < ps.pace_size) {
+        const int *w = ps.pace_grp + c - CC_GEMM_PACE_LEAD;
+        while (ps.pace_budget > 0 &&
+               __builtin_amdgcn_readfirstlane(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < ps.pace_size) {
+          __builtin_amdgcn_s_sleep(8);
+          --ps.pace_budget;
+        }
+      }
+      __hip_atomic_fetch_add(ps.pace_grp + c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (c + 1 >= CC_GEMM_PACE_LEAD)
+        ps.pace_seen = __hip_atomic_load(ps.pace_grp + c + 1 - CC_GEMM_PACE_LEAD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#endif
+#ifndef CC_GEMM_FAKE_NOSYNC
     __syncthreads();
+#endif
+#ifdef CC_GEMM_TRACE
+    if (KCLASS == 1 && tid == 0 && bid < 16384 && kt == KT / 2) g_gemm_trace[4 * bid + 1] = wall_clock64();
+#endif
   }
 }
 
@@ -135,7 +194,7 @@ __launch_bounds__(GEMM_THREADS)
 void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const float *__restrict__ A2,
                           int64_t lda2, int64_t M, const f32x4 *__restrict__ Wp,
                           const float *__restrict__ bias, int KT1, int KT, int N, int MT, int NT,
-                          float *__restrict__ C, int64_t ldc, int act) {
+                          float *__restrict__ C, int64_t ldc, int act, int *__restrict__ pace, int pace_nch) {
   constexpr int STAGE_FLOATS = BM * LDS_A_STRIDE + TILE_W_FLOAT4 * 4;
   __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
   float *As = lds;
@@ -153,11 +212,38 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   const int n_tile = (wgid % per_group) / gsz;
   const int64_t m0 = (int64_t)m_tile * BM;
   const int n0 = n_tile * BN;
+#if CC_GEMM_PACE
+  // Pacing group = the 32 workgroups dispatched back to back to this XCD (one per CU): the CU's wave
+  // arbiter serves its oldest workgroup first, so these advance through K at the same rate while the
+  // three workgroups sharing a CU do not (measured: K/2 reached at 1.95 / 3.08 / 3.29 ms).  Keeping a
+  // group within a few K-steps keeps its A/W panels (8 m-tiles x 4 n-tiles) in the XCD's L2.  Waiting is
+  // bounded (poll budget), so a group member that is not resident costs time, never progress.
+  int *pace_grp = nullptr;
+  int pace_size = 0, pace_budget = CC_GEMM_PACE_BUDGET, pace_seen = 0;
+  if (pace) {
+    const int n_local = q + (xcd < rem ? 1 : 0), j = bid >> 3;
+    const int grp = j >> 5;
+    pace_size = 64 * (n_local - 32 * grp < 32 ? n_local - 32 * grp : 32);   // every member adds 64 per chunk
+    pace_grp = pace + ((int64_t)xcd * ((q + 32) >> 5) + grp) * pace_nch;
+  }
+#endif
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int r = lane & 31, h = lane >> 5;
+#if CC_GEMM_PACE
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+#endif
+#ifdef CC_GEMM_TRACE
+  if (KCLASS == 1 && tid == 0 && bid < 16384) {
+    unsigned hw, xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g_gemm_trace[4 * bid + 0] = wall_clock64();
+    g_gemm_trace[4 * bid + 3] = ((unsigned long long)xcc << 32) | hw;
+  }
+#endif
 
   // ---- staging: per-thread running pointers into A (re-based once at the
   //      segment switch) and a scalar running pointer into the packed W tiles ----
@@ -171,12 +257,19 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   }
   const float *pa[NA];
   {
+#ifdef CC_GEMM_FAKE_A   // sensitivity probe: every workgroup reads the first m-tile's rows (results are wrong)
+    const int64_t m0 = 0;
+#endif
     const float *base = KT1 > 0 ? A1 + m0 * lda1 : A2 + m0 * lda2;
     const int lda = (int)(KT1 > 0 ? lda1 : lda2);
 #pragma unroll
     for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * lda + 4 * a_k4;
   }
+#ifdef CC_GEMM_FAKE_W   // sensitivity probe: every workgroup reads the first n-tile's weights (results are wrong)
+  const f32x4 *wt = Wp + tid;
+#else
   const f32x4 *wt = Wp + (int64_t)n_tile * KT * TILE_W_FLOAT4 + tid;
+#endif
 
   // The staging registers must stay in VGPRs (hipcc demotes them to scratch when
   // they are touched through lambdas or selected between arrays) so that the
@@ -219,7 +312,16 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   const float *a_lds = As + (wm * 64 + r) * LDS_A_STRIDE + 4 * h;
   const f32x4 *b_lds = Bs4 + h * BN + wn * 64 + r;
 
-  gemm_k_loop<KCLASS, 2, 2>(acc, ra, rb, pa, wt, a_lr, A2, m0, lda2, KT1, KT, As, Bs4, a_lds, b_lds, tid, a_row, a_k4);
+  PaceState ps;
+#if CC_GEMM_PACE
+  ps.pace_grp = pace_grp; ps.pace_size = pace_size; ps.pace_budget = pace_budget; ps.wave_u = wave_u;
+#endif
+#define CC_KLOOP(MV, NV) gemm_k_loop<KCLASS, MV, NV>(acc, ra, rb, pa, wt, a_lr, A2, m0, lda2, KT1, KT, As, Bs4, a_lds, b_lds, tid, a_row, a_k4, ps, bid)
+  CC_KLOOP(2, 2);
+#undef CC_KLOOP
+#ifdef CC_GEMM_TRACE
+  if (KCLASS == 1 && tid == 0 && bid < 16384) g_gemm_trace[4 * bid + 2] = wall_clock64();
+#endif
 
   // ---- epilogue: bias + activation, 128-byte row segments per half-wave ------
 #pragma unroll
@@ -318,11 +420,31 @@ int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, in
   const int64_t MT = ceil_div(M, BM);
   const int64_t nwg = MT * W.NT;
   CC_REQUIRE(nwg < (int64_t)2147483647, "gemm: grid too large");
+  // pacing counters: [8 XCDs][groups of 32 workgroups][chunks of K-steps], zeroed per launch
+  int *pace = nullptr;
+  int pace_nch = 0;
+#if CC_GEMM_PACE
+  static int *pace_buf = nullptr;
+  static size_t pace_cap = 0;
+  if (g_gemm_pace && prof_class != CC_PROF_GEMM_TAIL && nwg >= 512) {
+    pace_nch = (int)ceil_div(W.KT1 + W.KT2, CC_GEMM_PACE_EVERY);
+    const size_t need = sizeof(int) * 8 * (size_t)(((nwg >> 3) + 32) >> 5) * (size_t)pace_nch;
+    if (need > pace_cap) {
+      if (pace_buf) (void)hipFree(pace_buf);
+      pace_buf = nullptr;
+      pace_cap = 0;
+      CC_HIP(hipMalloc(&pace_buf, need));
+      pace_cap = need;
+    }
+    CC_HIP(hipMemsetAsync(pace_buf, 0, need, stream()));
+    pace = pace_buf;
+  }
+#endif
   ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
 #define CC_LAUNCH_GEMM(KC)                                                                                  \
   hipLaunchKernelGGL(gemm_bias_act_kernel<KC>, dim3((unsigned)nwg), dim3(GEMM_THREADS), 0, stream(), A1,    \
                      lda1, A2, lda2, M, reinterpret_cast<const f32x4 *>(W.d_w), W.d_bias, (int)W.KT1,     \
-                     (int)(W.KT1 + W.KT2), (int)W.N, (int)MT, (int)W.NT, C, ldc, act)
+                     (int)(W.KT1 + W.KT2), (int)W.N, (int)MT, (int)W.NT, C, ldc, act, pace, pace_nch)
   if (prof_class == CC_PROF_GEMM_L1) CC_LAUNCH_GEMM(1);
   else if (prof_class == CC_PROF_GEMM_L2) CC_LAUNCH_GEMM(2);
   else CC_LAUNCH_GEMM(3);
@@ -330,6 +452,15 @@ int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, in
   CC_HIP(hipGetLastError());
   return CC_OK;
 }
+
+#ifdef CC_GEMM_TRACE
+}  // namespace cc
+extern "C" int cc_debug_gemm_trace(unsigned long long *out, int n_wg) {
+  CC_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(cc::g_gemm_trace), sizeof(unsigned long long) * 4 * (size_t)n_wg));
+  return CC_OK;
+}
+namespace cc {
+#endif
 
 // ---- row softmax (classify encoder's last activation,
 //      reference src/bigan_classify.py:39) ------------------------------------

@@ -145,6 +145,17 @@ __global__ __launch_bounds__(THREADS, 1) void spmm_kernel(const Entry *__restric
       const int m = n - c0 < 64 ? n - c0 : 64;
       if (VARIANT == 0 || VARIANT == 2) {
         int i = 0;
+#ifndef ABL
+#define ABL 0
+#endif
+#if ABL == 1 || ABL == 3   // ablation: no FMAs (operands kept alive so the loads are not dead code)
+#undef FMA16_IDX
+#define FMA16_IDX(acc0, acc1, i0, i1, i2, i3, v0, v1, v2, v3, b0, b1, b2, b3) \
+  asm volatile("" :: "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(v0), "s"(v1), "s"(v2), "s"(v3), "v"(b0), "v"(b1), "v"(b2), "v"(b3))
+#endif
+#if ABL == 2 || ABL == 3   // ablation: no weight reads from LDS
+#define lds_read4(p) (f32x4{1.f, 2.f, 3.f, 4.f})
+#endif
 #define RL_CODE(j) __builtin_amdgcn_readlane(cur.code, (j))
 #define RL_VAL(j) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur.val), (j)))
         if (VARIANT == 2) {
@@ -206,10 +217,158 @@ __global__ __launch_bounds__(THREADS, 1) void spmm_kernel(const Entry *__restric
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if ABL != 4
     __syncthreads();
+#endif
   }
 
   // epilogue: bias + sigmoid, 1 KiB per row per wave
+  const int col = panel * NT + lane * 4;
+  const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + col);
+#pragma unroll
+  for (int r = 0; r < RW; ++r) {
+    const int64_t row = (int64_t)rb * ROWS + wave * RW + r;
+    f32x4 z;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float a = (r < 8 ? acc0[4 * (r & 7) + j] : acc1[4 * (r & 7) + j]) + bv[j];
+      z[j] = 1.f / (1.f + __expf(-a));
+    }
+    if (col + 3 < ldo) *reinterpret_cast<f32x4 *>(out + row * ldo + col) = z;
+  }
+}
+
+
+// ---- variant 3: entries through the scalar cache, the per-stage loop hand-scheduled ---------------------------
+// A wave's entries of a stage are a run of 4-entry groups (32 bytes: code0 val0 ... code3 val3; short runs are padded
+// with entries that multiply a zero row of the LDS stage by 0).  s_load_dwordx8 brings a group straight into SGPRs —
+// no v_readlane — two groups ahead; the weights of group g+1 are read from LDS while the 16 FMAs of group g issue.
+// code = byte offset of the k-row in the stage (17 bits; row 64 = zeros) | (4 * row_local) << 17.
+constexpr int STAGE3_BYTES = (KB + 1) * NT * 4;   // 64 weight rows + the zero row
+constexpr int LDS3_BYTES = 2 * STAGE3_BYTES;
+
+#define F4(acc, sv, b0, b1, b2, b3) \
+  "v_fma_f32 v64, " sv ", " b0 ", v64\n\t" "v_fma_f32 v65, " sv ", " b1 ", v65\n\t" \
+  "v_fma_f32 v66, " sv ", " b2 ", v66\n\t" "v_fma_f32 v67, " sv ", " b3 ", v67\n\t"
+
+__global__ __launch_bounds__(THREADS, 1) void spmm_asm_kernel(const Entry *__restrict__ ent, const int *__restrict__ goffs,
+                                                              const float *__restrict__ Wp, const float *__restrict__ bias,
+                                                              int K, int nstages, int nrb, float *__restrict__ out,
+                                                              int64_t ldo) {
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int panel = blockIdx.x / nrb, rb = blockIdx.x % nrb;
+  const float *wsrc = Wp + (int64_t)panel * K * NT + lane * 4;
+  const int *my_offs = goffs + (int64_t)(rb * WAVES + wave) * (nstages + 1);
+
+  f32x32 acc0, acc1;
+#pragma unroll
+  for (int i = 0; i < 32; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+  if (tid < 128) {   // the two zero rows
+    const int buf = tid >> 6;
+    *reinterpret_cast<f32x4 *>(smem + buf * STAGE3_BYTES + KB * NT * 4 + (tid & 63) * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  auto issue = [&](int s, int buf) {
+    char *dst = smem + buf * STAGE3_BYTES;
+#pragma unroll
+    for (int i = 0; i < KB / WAVES; ++i) {
+      const int kl = i * WAVES + wave;
+      int k = s * KB + kl;
+      k = k < K ? k : K - 1;
+      GLDS(wsrc + (int64_t)k * NT, dst + kl * (NT * 4));
+    }
+  };
+
+  int gpos = my_offs[0];
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int s = 0; s < nstages; ++s) {
+    const int gend = my_offs[s + 1];
+    if (s + 1 < nstages) issue(s + 1, (s + 1) & 1);
+    int vbase = (s & 1) * STAGE3_BYTES + lane * 16;
+    int n = gend - gpos;
+    const Entry *ep = ent + (int64_t)gpos * 4;
+    gpos = gend;
+    if (n > 0) {
+      asm volatile(
+          "s_mov_b32 s88, m0\n\t"
+          "s_load_dwordx8 s[60:67], s[90:91], 0x0\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "s_and_b32 s84, s60, 0x1ffff\n\t" "s_and_b32 s85, s62, 0x1ffff\n\t"
+          "s_and_b32 s86, s64, 0x1ffff\n\t" "s_and_b32 s87, s66, 0x1ffff\n\t"
+          "v_add_u32 v28, s84, %[vb]\n\t" "v_add_u32 v29, s85, %[vb]\n\t"
+          "v_add_u32 v30, s86, %[vb]\n\t" "v_add_u32 v31, s87, %[vb]\n\t"
+          "ds_read_b128 v[32:35], v28\n\t" "ds_read_b128 v[36:39], v29\n\t"
+          "ds_read_b128 v[40:43], v30\n\t" "ds_read_b128 v[44:47], v31\n\t"
+          "s_load_dwordx8 s[68:75], s[90:91], 0x20\n\t"
+          "1:\n\t"
+          // even step: FMAs of the group in s[60:67] on v[32:47]; next weights from s[68:75] into v[48:63]
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "s_lshr_b32 s76, s60, 17\n\t" "s_lshr_b32 s77, s62, 17\n\t" "s_lshr_b32 s78, s64, 17\n\t" "s_lshr_b32 s79, s66, 17\n\t"
+          "s_mov_b32 s80, s61\n\t" "s_mov_b32 s81, s63\n\t" "s_mov_b32 s82, s65\n\t" "s_mov_b32 s83, s67\n\t"
+          "s_load_dwordx8 s[60:67], s[90:91], 0x40\n\t"
+          "s_and_b32 s84, s68, 0x1ffff\n\t" "s_and_b32 s85, s70, 0x1ffff\n\t"
+          "s_and_b32 s86, s72, 0x1ffff\n\t" "s_and_b32 s87, s74, 0x1ffff\n\t"
+          "v_add_u32 v28, s84, %[vb]\n\t" "v_add_u32 v29, s85, %[vb]\n\t"
+          "v_add_u32 v30, s86, %[vb]\n\t" "v_add_u32 v31, s87, %[vb]\n\t"
+          "ds_read_b128 v[48:51], v28\n\t" "ds_read_b128 v[52:55], v29\n\t"
+          "ds_read_b128 v[56:59], v30\n\t" "ds_read_b128 v[60:63], v31\n\t"
+          "s_set_gpr_idx_on s76, 0xc\n\t"
+          F4(, "s80", "v32", "v33", "v34", "v35")
+          "s_set_gpr_idx_idx s77\n\t"
+          F4(, "s81", "v36", "v37", "v38", "v39")
+          "s_set_gpr_idx_idx s78\n\t"
+          F4(, "s82", "v40", "v41", "v42", "v43")
+          "s_set_gpr_idx_idx s79\n\t"
+          F4(, "s83", "v44", "v45", "v46", "v47")
+          "s_set_gpr_idx_off\n\t"
+          "s_sub_u32 %[n], %[n], 1\n\t"
+          "s_cmp_eq_u32 %[n], 0\n\t"
+          "s_cbranch_scc1 2f\n\t"
+          // odd step: FMAs of the group in s[68:75] on v[48:63]; next weights from s[60:67] into v[32:47]
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "s_lshr_b32 s76, s68, 17\n\t" "s_lshr_b32 s77, s70, 17\n\t" "s_lshr_b32 s78, s72, 17\n\t" "s_lshr_b32 s79, s74, 17\n\t"
+          "s_mov_b32 s80, s69\n\t" "s_mov_b32 s81, s71\n\t" "s_mov_b32 s82, s73\n\t" "s_mov_b32 s83, s75\n\t"
+          "s_load_dwordx8 s[68:75], s[90:91], 0x60\n\t"
+          "s_and_b32 s84, s60, 0x1ffff\n\t" "s_and_b32 s85, s62, 0x1ffff\n\t"
+          "s_and_b32 s86, s64, 0x1ffff\n\t" "s_and_b32 s87, s66, 0x1ffff\n\t"
+          "v_add_u32 v28, s84, %[vb]\n\t" "v_add_u32 v29, s85, %[vb]\n\t"
+          "v_add_u32 v30, s86, %[vb]\n\t" "v_add_u32 v31, s87, %[vb]\n\t"
+          "ds_read_b128 v[32:35], v28\n\t" "ds_read_b128 v[36:39], v29\n\t"
+          "ds_read_b128 v[40:43], v30\n\t" "ds_read_b128 v[44:47], v31\n\t"
+          "s_set_gpr_idx_on s76, 0xc\n\t"
+          F4(, "s80", "v48", "v49", "v50", "v51")
+          "s_set_gpr_idx_idx s77\n\t"
+          F4(, "s81", "v52", "v53", "v54", "v55")
+          "s_set_gpr_idx_idx s78\n\t"
+          F4(, "s82", "v56", "v57", "v58", "v59")
+          "s_set_gpr_idx_idx s79\n\t"
+          F4(, "s83", "v60", "v61", "v62", "v63")
+          "s_set_gpr_idx_off\n\t"
+          "s_add_u32 s90, s90, 0x40\n\t"
+          "s_addc_u32 s91, s91, 0\n\t"
+          "s_sub_u32 %[n], %[n], 1\n\t"
+          "s_cmp_eq_u32 %[n], 0\n\t"
+          "s_cbranch_scc0 1b\n\t"
+          "2:\n\t"
+          "s_waitcnt lgkmcnt(0)\n\t"
+          "s_mov_b32 m0, s88\n\t"
+          "s_nop 0"
+          : "+{v[64:95]}"(acc0), "+{v[96:127]}"(acc1), [n] "+s"(n), "+{s[90:91]}"(ep)
+          : [vb] "v"(vbase)
+          : "memory", "scc", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41",
+            "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57",
+            "v58", "v59", "v60", "v61", "v62", "v63", "s60", "s61", "s62", "s63", "s64", "s65", "s66", "s67", "s68", "s69",
+            "s70", "s71", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85",
+            "s86", "s87", "s88");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
   const int col = panel * NT + lane * 4;
   const f32x4 bv = *reinterpret_cast<const f32x4 *>(bias + col);
 #pragma unroll
@@ -305,6 +464,31 @@ int main(int argc, char **argv) {
   if (max_cnt > 128) { printf("a (wave, stage) list exceeds 128 entries\n"); return 1; }
   if (ent.size() > 0x7fffffffull) { printf("stream too long for int offsets\n"); return 1; }
 
+  if (variant == 3) {
+    // 4-entry groups, short runs padded with (zero row, value 0); offsets count groups
+    ent.clear();
+    std::vector<int64_t> cur2(RW);
+    for (int rbw = 0; rbw < nrb * WAVES; ++rbw) {
+      const int64_t row0 = (int64_t)rbw * RW;
+      for (int r = 0; r < RW; ++r) cur2[r] = indptr[row0 + r];
+      for (int st = 0; st < nstages; ++st) {
+        offs[(size_t)rbw * (nstages + 1) + st] = (int)(ent.size() / 4);
+        const int kend = (st + 1) * KB;
+        for (int r = 0; r < RW; ++r) {
+          int64_t &c = cur2[r];
+          while (c < indptr[row0 + r + 1] && cols[c] < kend) {
+            ent.push_back({(uint32_t)((cols[c] - st * KB) * (NT * 4)) | ((uint32_t)(r * 4) << 17), vals[c]});
+            ++c;
+          }
+        }
+        while (ent.size() % 4) ent.push_back({(uint32_t)(KB * NT * 4), 0.f});
+      }
+      offs[(size_t)rbw * (nstages + 1) + nstages] = (int)(ent.size() / 4);
+    }
+    for (int i = 0; i < 64; ++i) ent.push_back({(uint32_t)(KB * NT * 4), 0.f});   // the loop loads two groups ahead
+    printf("variant 3 stream: %zu entries (%.1f%% padding)\n", ent.size(), 100.0 * (ent.size() - nnz) / nnz);
+  }
+
   Entry *d_ent; int *d_offs; float *d_Wp, *d_b, *d_out;
   CHECK(hipMalloc(&d_ent, ent.size() * sizeof(Entry)));
   CHECK(hipMalloc(&d_offs, offs.size() * sizeof(int)));
@@ -317,8 +501,9 @@ int main(int argc, char **argv) {
   CHECK(hipMemcpy(d_b, b.data(), b.size() * sizeof(float), hipMemcpyHostToDevice));
   CHECK(hipMemset(d_out, 0, (size_t)M * ldo * sizeof(float)));
 
-  auto kern = variant == 0 ? spmm_kernel<0> : variant == 1 ? spmm_kernel<1> : spmm_kernel<2>;
-  CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES));
+  auto kern = variant == 0 ? spmm_kernel<0> : variant == 1 ? spmm_kernel<1> : variant == 2 ? spmm_kernel<2> : spmm_asm_kernel;
+  const int lds_bytes = variant == 3 ? LDS3_BYTES : LDS_BYTES;
+  CHECK(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   hipEvent_t e0, e1;
   CHECK(hipEventCreate(&e0));
   CHECK(hipEventCreate(&e1));
@@ -326,7 +511,7 @@ int main(int argc, char **argv) {
   float best = 1e30f;
   for (int it = 0; it < 4; ++it) {
     CHECK(hipEventRecord(e0));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), LDS_BYTES, 0, d_ent, d_offs, d_Wp, d_b, K, nstages, nrb, d_out, ldo);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(THREADS), lds_bytes, 0, d_ent, d_offs, d_Wp, d_b, K, nstages, nrb, d_out, ldo);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     CHECK(hipGetLastError());

@@ -15,6 +15,8 @@ reps = int(sys.argv[5]) if len(sys.argv) > 5 else 3
 _lib.ensure_init(0)
 if os.environ.get('CC_FULL'):
     _lib.lib().cc_knn_force_full_select(1)   # route 1a whatever the size
+if os.environ.get('CC_KNN_COLLECT_SPLITS'):  # sweep knob (tools/knn_split_sweep.sh): an option of the workspace, not an env read in the library
+    _lib.check(_lib.lib().cc_knn_set_option(None, 5, int(os.environ['CC_KNN_COLLECT_SPLITS'])))
 x = torch.rand((n, d), device='cuda'); torch.cuda.synchronize()
 knn_graph_device(x.data_ptr(), n, d, k, 0, nq)
 _lib.profile_enable(True); _lib.profile_reset()
