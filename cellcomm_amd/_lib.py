@@ -15,7 +15,7 @@ _LIB = None
 _INIT_DEVICE = None
 
 PROF_CLASSES = ['gather', 'gemm_l1', 'gemm_l2', 'gemm_tail', 'softmax',
-                'knn_pack', 'knn_select', 'knn_rerank', 'knn_fallback']
+                'knn_pack', 'knn_select', 'knn_rerank', 'knn_fallback', 'spmm_l1', 'spmm_l2']
 
 
 class HipUnavailable(RuntimeError):
@@ -42,6 +42,7 @@ SIGNATURES = {
     'cc_encoder_set_weights': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64]),
     'cc_encoder_set_batch': (c_int, [c_void_p, c_int64]),
     'cc_encoder_fp32_fallback_passes': (c_int64, [c_void_p]),
+    'cc_encoder_set_sparse_input': (c_int, [c_void_p, c_int]),
     'cc_generator_create': (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     'cc_generator_free': (None, [c_void_p]),
     'cc_generator_num_weights': (c_int, [c_void_p]),

@@ -86,6 +86,7 @@ struct Csr {
   int64_t n_rows = 0, nnz = 0;
   int G = 0;
   bool owned = false;
+  SpmmStream stream;             // the non-zeros in the order the sparse first layer consumes them (built on first use)
 };
 
 static int csr_build_index(Csr *c) {
@@ -111,6 +112,13 @@ struct Encoder {
   // layers run once over n rows instead of once per pass (39 -> 3 launches at 100k cells)
   int64_t tail_rows = 0;
   float *h2_all = nullptr, *h3_all = nullptr, *h4_all = nullptr;
+  // sparse first layer (cc_encoder_set_sparse_input): x @ K1 and the raw-input rows of K2 as CSR x dense products
+  // on the vector ALUs; the whole call is one pass, so layer 1's output is kept for all rows too
+  bool sparse = false;
+  SpmmWeight S1, S2;
+  PackedWeight L2a;                // cont: the hidden-activation rows of K2 (+ b2) for the dense MFMA part of layer 2
+  float *h1_all = nullptr;
+  int64_t h1_rows = 0;
   int64_t fallback_passes = 0;
   int64_t w0 = 0, w1 = 0;  // hidden widths of the first two layers
   int64_t batch = 8192;
@@ -187,6 +195,14 @@ static int encoder_pack(Encoder *e) {
     if ((rc = pack_weight(e->w[4].data(), e->w[5].data(), 300, 1000, 150, &e->L[2]))) return rc;
     if ((rc = pack_weight(e->w[6].data(), e->w[7].data(), 150, 0, e->E, &e->L[3]))) return rc;
   }
+  if (e->sparse && e->w0 > 0 && e->w1 > 0) {
+    if ((rc = pack_spmm_weight(e->w[0].data(), e->w[1].data(), e->G, e->w0, &e->S1))) return rc;
+    if (e->arch == CC_ARCH_CONT) {
+      // K2 rows [0, w0) multiply the hidden activation (dense MFMA), rows [w0, w0 + G) the raw counts (sparse)
+      if ((rc = pack_weight(e->w[2].data(), e->w[3].data(), e->w0, 0, e->w1, &e->L2a))) return rc;
+      if ((rc = pack_spmm_weight(e->w[2].data() + e->w0 * e->w1, nullptr, e->G, e->w1, &e->S2))) return rc;
+    }
+  }
   if (e->dtype != CC_DTYPE_F32) {
     // layers 1-2 again, split into fp16 hi/lo planes for the fp16 matrix cores
     if (e->arch == CC_ARCH_CONT) {
@@ -197,6 +213,13 @@ static int encoder_pack(Encoder *e) {
     }
   }
   e->dirty = false;
+  return CC_OK;
+}
+
+static int alloc_zero(float **p, int64_t rows, int64_t ld) {
+  const size_t bytes = sizeof(float) * (size_t)(rows * ld);
+  CC_HIP(hipMalloc(p, bytes));
+  CC_HIP(hipMemsetAsync(*p, 0, bytes, stream()));
   return CC_OK;
 }
 
@@ -218,19 +241,64 @@ static void encoder_free_ws(Encoder *e) {
     e->d_row_ids[sl] = nullptr;
   }
   e->ws_slots = 0;
-  float **tb[] = {&e->h2_all, &e->h3_all, &e->h4_all};
+  float **tb[] = {&e->h2_all, &e->h3_all, &e->h4_all, &e->h1_all};
   for (auto b : tb) {
     if (*b) (void)hipFree(*b);
     *b = nullptr;
   }
   e->tail_rows = 0;
+  e->h1_rows = 0;
   e->ws_rows = 0;
 }
 
-static int alloc_zero(float **p, int64_t rows, int64_t ld) {
-  const size_t bytes = sizeof(float) * (size_t)(rows * ld);
-  CC_HIP(hipMalloc(p, bytes));
-  CC_HIP(hipMemsetAsync(*p, 0, bytes, stream()));
+// [n x ld] buffers for calls that keep an activation of ALL rows (tail layers once per call; the sparse path)
+static int encoder_ensure_all_rows(Encoder *e, int64_t n, bool with_h1) {
+  int rc;
+  if (n > e->tail_rows) {
+    float **tb[] = {&e->h2_all, &e->h3_all, &e->h4_all};
+    for (auto b : tb) {
+      if (*b) (void)hipFree(*b);
+      *b = nullptr;
+    }
+    e->tail_rows = 0;
+    if ((rc = alloc_zero(&e->h2_all, n, e->ld2))) return rc;
+    if ((rc = alloc_zero(&e->h3_all, n, e->ld3))) return rc;
+    if ((rc = alloc_zero(&e->h4_all, n, e->ld3))) return rc;
+    e->tail_rows = n;
+  }
+  if (with_h1 && n > e->h1_rows) {
+    if (e->h1_all) (void)hipFree(e->h1_all);
+    e->h1_all = nullptr;
+    e->h1_rows = 0;
+    if ((rc = alloc_zero(&e->h1_all, n, e->ld1))) return rc;
+    e->h1_rows = n;
+  }
+  return CC_OK;
+}
+
+// Sparse first layer: the whole range in one pass, no dense copy of the counts (reference graphs
+// src/bigan_cont.py:32-41, src/bigan_classify.py:31-39; see spmm.hip).
+static int encode_csr_sparse(Encoder *e, Csr *c, int64_t row_start, int64_t n, float *dev_out) {
+  int rc;
+  if (!c->stream.d_offs && (rc = build_spmm_stream(c->indptr, c->indices, c->vals, c->n_rows, c->G, &c->stream))) return rc;
+  e->ldx = pad32(e->G); e->ld1 = pad32(e->w0); e->ld2 = pad32(e->w1); e->ld3 = pad32(150);
+  if ((rc = encoder_ensure_all_rows(e, n, true))) return rc;
+  const double nnz_hint = c->n_rows ? (double)c->nnz / (double)c->n_rows * (double)n : 0.0;
+  if ((rc = launch_spmm(c->stream, row_start, n, e->S1, nullptr, 0, e->h1_all, e->ld1, ACT_SIGMOID, CC_PROF_SPMM_L1, nnz_hint))) return rc;
+  if (e->arch == CC_ARCH_CONT) {
+    // layer 2 = sigmoid(h1 @ K2[:w0] + b2  (dense MFMA, linear)  +  x @ K2[w0:]  (sparse, adds the dense part, activates))
+    if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, n, e->L2a, e->h2_all, e->ld2, ACT_LINEAR, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_spmm(c->stream, row_start, n, e->S2, e->h2_all, e->ld2, e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_SPMM_L2, nnz_hint))) return rc;
+    if ((rc = launch_gemm(e->h2_all, e->ld2, nullptr, 0, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], e->h4_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h4_all, e->ld3, nullptr, 0, n, e->L[4], dev_out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+  } else {
+    if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, n, e->L[1], e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->h2_all, e->ld2, e->h1_all, e->ld1, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], dev_out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_row_softmax(dev_out, n, e->E, e->E))) return rc;
+  }
+  CC_HIP(hipStreamSynchronize(stream()));
   return CC_OK;
 }
 
@@ -348,6 +416,10 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   if (e->dirty && (rc = encoder_pack(e))) return rc;
   e->fallback_passes = 0;
   if (n == 0) return CC_OK;
+  // contiguous rows of a matrix through the sparse first layer; sampled rows (minibatches) and degenerate widths
+  // (int(G*0.1) == 0) keep the gather + dense path
+  if (e->sparse && e->dtype == CC_DTYPE_F32 && !row_ids && e->w0 > 0 && e->w1 > 0)
+    return encode_csr_sparse(e, c, row_start, n, dev_out);
   // Pass plan.  GEMM time is quantised in rounds of 768 resident tiles, so a short pass leaves most
   // CUs idle in its final round.  Calls of 2-4 passes (the per-rank shards at 4 and 8 GPUs) are cut
   // into equal passes that alternate between two streams with their own workspaces: the idle CUs of
@@ -378,17 +450,7 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   if ((rc = encoder_ensure_ws(e, B, dual ? 2 : 1))) return rc;
   const double nnz_per_row = c->n_rows ? (double)c->nnz / (double)c->n_rows : 0.0;
   const bool tail_once = e->arch == CC_ARCH_CONT && n > B;
-  if (tail_once && n > e->tail_rows) {
-    float **tb[] = {&e->h2_all, &e->h3_all, &e->h4_all};
-    for (auto b : tb) {
-      if (*b) (void)hipFree(*b);
-      *b = nullptr;
-    }
-    if ((rc = alloc_zero(&e->h2_all, n, e->ld2))) return rc;
-    if ((rc = alloc_zero(&e->h3_all, n, e->ld3))) return rc;
-    if ((rc = alloc_zero(&e->h4_all, n, e->ld3))) return rc;
-    e->tail_rows = n;
-  }
+  if (tail_once && (rc = encoder_ensure_all_rows(e, n, false))) return rc;
   if (dual) CC_HIP(hipStreamSynchronize(g_stream));   // workspace / h2_all memsets are on the library stream
   struct StreamReset { ~StreamReset() { g_cur = nullptr; } } stream_reset;
   if (lead_passes > 0 && !g_lead_done) CC_HIP(hipEventCreateWithFlags(&g_lead_done, hipEventDisableTiming));
@@ -537,6 +599,9 @@ void cc_encoder_free(void *enc) {
   encoder_free_ws(e);
   for (auto &l : e->L) free_weight(&l);
   for (auto &l : e->L16) free_weight16(&l);
+  free_weight(&e->L2a);
+  free_spmm_weight(&e->S1);
+  free_spmm_weight(&e->S2);
   delete e;
 }
 
@@ -560,6 +625,14 @@ int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, 
   e->w[idx].assign(host, host + count);
   e->have[idx] = true;
   e->dirty = true;
+  return CC_OK;
+}
+
+int cc_encoder_set_sparse_input(void *enc, int on) {
+  Encoder *e = static_cast<Encoder *>(enc);
+  CC_REQUIRE(!on || e->dtype == CC_DTYPE_F32, "the sparse first layer computes in fp32: create the encoder with CC_DTYPE_F32");
+  if (e->sparse != (on != 0)) e->dirty = true;   // the panel-packed weights are made at the next pack
+  e->sparse = on != 0;
   return CC_OK;
 }
 
@@ -618,6 +691,7 @@ void cc_csr_free(void *csr) {
   if (!csr) return;
   Csr *c = static_cast<Csr *>(csr);
   if (c->chunk_rel) (void)hipFree(c->chunk_rel);
+  free_spmm_stream(&c->stream);
   if (c->owned) {
     if (c->indptr) (void)hipFree(c->indptr);
     if (c->indices) (void)hipFree(c->indices);
@@ -682,8 +756,10 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
   if (e->dirty && (rc = encoder_pack(e))) return rc;
   e->fallback_passes = 0;
   if (n == 0) return CC_OK;
-  // passes of at most 2048 rows keep the first (un-overlapped) copy short; one pass when everything fits
-  const int64_t B = n < 2048 ? n : (e->batch < 2048 ? e->batch : 2048);
+  // passes of at most 2048 rows (or the encoder's own pass size when that is smaller) keep the first,
+  // un-overlapped copy short
+  const int64_t cap = e->batch < 2048 ? e->batch : 2048;
+  const int64_t B = n < cap ? n : cap;
   const int64_t npass = ceil_div(n, B);
   const int slots = npass > 1 ? 2 : 1;
   if ((rc = encoder_ensure_ws(e, B, slots))) return rc;

@@ -139,6 +139,29 @@ int launch_gather_f16(const int64_t *d_indptr, const int32_t *d_indices, const f
 // indptr monotone from 0 to nnz, columns of a row strictly increasing and inside [0, G)
 int validate_csr(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_rows, int64_t nnz, int G);
 
+// spmm.hip — sparse-aware first layer: CSR rows x fp32 weight panels on the vector ALUs
+constexpr int SPMM_ROWS = 256, SPMM_KB = 64, SPMM_NT = 256;
+struct SpmmWeight {
+  float *d_w = nullptr;      // [npan][K][256] fp32, zero beyond N
+  float *d_bias = nullptr;   // [N] or NULL
+  int64_t K = 0, N = 0, npan = 0;
+};
+struct SpmmStream {           // the matrix's non-zeros re-ordered per 16-row group by (64-column stage, row, column)
+  void *d_ent = nullptr;      // {code, value} pairs
+  int *d_offs = nullptr;      // [ngroups][nstages + 1] stream index of each (group, stage); bit 0 = padded
+  int64_t n_rows = 0, n_entries = 0, ngroups = 0;
+  int G = 0, nstages = 0;
+};
+// w_rows: [K x N] row-major host weights (rows that multiply the raw counts), bias: [N] or NULL
+int pack_spmm_weight(const float *w_rows, const float *bias, int64_t K, int64_t N, SpmmWeight *out);
+void free_spmm_weight(SpmmWeight *w);
+int build_spmm_stream(const int64_t *d_indptr, const int32_t *d_indices, const float *d_vals, int64_t n_rows, int G,
+                      SpmmStream *st);
+void free_spmm_stream(SpmmStream *st);
+// C[n x N] (ldc) = act(X[row_start : row_start + n] @ W (+ addend[n x N] (ld_add)) + bias)
+int launch_spmm(const SpmmStream &st, int64_t row_start, int64_t n, const SpmmWeight &W, const float *addend,
+                int64_t ld_add, float *C, int64_t ldc, int act, int prof_class, double nnz_hint);
+
 // knn.hip — ws == nullptr: the library's default workspace (released by cc_shutdown)
 struct KnnWorkspace;
 KnnWorkspace *knn_default_ws();

@@ -74,7 +74,7 @@ def _layer_plan(arch, encoding_size, gene_size):
 class HipEncoder:
     name = 'cell_encoder'
 
-    def __init__(self, encoding_size, gene_size, arch=ARCH_CONT, seed=None, batch_rows=None, dtype='f32'):
+    def __init__(self, encoding_size, gene_size, arch=ARCH_CONT, seed=None, batch_rows=None, dtype='f32', sparse=False):
         if arch not in _ARCH_CODE:
             raise ValueError(f'unknown encoder arch {arch!r}')
         if dtype not in _DTYPE_CODE:
@@ -92,6 +92,13 @@ class HipEncoder:
                                          ctypes.byref(self._h)))
         if batch_rows:
             _lib.check(lib.cc_encoder_set_batch(self._h, int(batch_rows)))
+        # sparse=True: CellMatrix rows in storage order never get densified — the products with the raw counts run
+        # over the non-zeros only (fp32, csrc/spmm.hip); sampled rows and dense input keep the gather + dense path
+        self.sparse = bool(sparse)
+        if self.sparse:
+            if dtype != 'f32':
+                raise ValueError('sparse=True computes in fp32: use dtype="f32"')
+            _lib.check(lib.cc_encoder_set_sparse_input(self._h, 1))
         self._shapes = []
         for i in range(lib.cc_encoder_num_weights(self._h)):
             r, c = ctypes.c_int64(), ctypes.c_int64()

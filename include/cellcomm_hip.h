@@ -82,6 +82,13 @@ int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols);
 int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols);
 /* Rows processed per pass through the layer stack (default 8192 for CC_DTYPE_F32, 16384 for the fp16 dtypes). */
 int cc_encoder_set_batch(void *enc, int64_t batch_rows);
+/* Sparse first layer (CC_DTYPE_F32 encoders only, default off).  When on, cc_encode /
+ * cc_encode_dev of a CONTIGUOUS row range (row_ids == NULL) never densify the counts: x @ K1 and the raw-input
+ * rows of K2 (reference src/bigan_cont.py:32-35, src/bigan_classify.py:31) run as CSR x dense products in fp32 on
+ * the vector ALUs over the non-zeros only; the hidden-activation rows of K2 and the later layers stay on the fp32
+ * matrix cores.  Same arithmetic type and tolerance as the dense path (summation order differs); sampled rows
+ * and dense host input keep the gather + dense GEMM path. */
+int cc_encoder_set_sparse_input(void *enc, int on);
 /* fp16 dtypes: passes of the last cc_encode* call that ran on the fp32 kernels instead — CC_DTYPE_F16X2:
  * some value of the pass is not exactly an fp16 number; CC_DTYPE_F16: some value lies outside the fp16
  * range (|v| > 65504 would become inf and turn the row into NaN). */
@@ -231,7 +238,9 @@ int cc_duplicate_representatives(const float *host_xyz, int64_t n, int32_t *host
 #define CC_PROF_KNN_SELECT 6
 #define CC_PROF_KNN_RERANK 7
 #define CC_PROF_KNN_FALLBACK 8
-#define CC_PROF_NUM 9
+#define CC_PROF_SPMM_L1 9   /* sparse first layer: x @ K1 (work = 2 * nnz * N FLOP) */
+#define CC_PROF_SPMM_L2 10  /* sparse raw-input segment of layer 2                 */
+#define CC_PROF_NUM 11
 
 /* When enabled every kernel launch is bracketed by HIP events on the library
  * stream; totals accumulate until cc_profile_reset(). */

@@ -82,6 +82,53 @@ def test_config4_shard_of_1m_candidates(hip, oracle_built):
     assert np.all(idx != (q_begin + np.arange(n_q))[:, None]) and np.all(np.diff(dist, axis=1) >= 0)
 
 
+def test_config4_one_ranks_encode_125k_rows(hip):
+    # configs[3]: one rank's encode (125k of the 1M cells, G = 30000, latent 64).  Full-size truth is not affordable on
+    # the host, so: 48 sampled rows against the float64 oracle, plus properties — idempotence, independence of a row
+    # from its pass (8192-row passes: 15 full + 1 of 2120 rows) and from the call it sits in.
+    n, g, e = 125000, 30000, 64
+    m, (indptr, indices, values) = synth.synth_csr_device(n, g, seed=77)
+    enc = cc.HipEncoder(e, g, 'cont', seed=4321)
+    out = enc.predict(m)
+    assert out.shape == (n, e) and np.all(np.isfinite(out)) and np.all(out > 0) and np.all(out < 1)
+    assert np.array_equal(enc.predict(m), out)
+    host = cc.CellMatrix(indptr.cpu().numpy(), indices.cpu().numpy(), values.cpu().numpy(), g)
+    rows = np.random.default_rng(4).choice(n, 48, replace=False)
+    assert max_rel(out[rows], eo.forward('cont', enc.get_weights(), host.take(rows).to_dense())) <= 1e-4
+    tail = host.take(np.arange(122000, n))                       # crosses the last full pass into the short one
+    assert np.array_equal(enc.predict(tail), out[122000:])
+    assert np.array_equal(enc.predict(host.take(rows)), out[rows])
+
+
+def test_config5_one_ranks_knn_62500_queries_of_500k_k50(hip, oracle_built):
+    # configs[4]: 500k cells over 8 GPUs, k = 50 — one rank's REAL search shape: its 62 500 queries against all
+    # 500 000 candidates (only 62.5k x 62.5k had been run).  48 sampled queries bit-exact against
+    # oracle/knn_oracle.c, plus properties over all 62 500 lists.
+    import torch
+    n, d, k = 500000, 64, 50
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(21)
+    x = torch.sigmoid(torch.randn((n, d), device='cuda', generator=gen))
+    x[250000:250040] = x[123]                                     # a run of exact duplicates inside the query block
+    torch.cuda.synchronize()
+    q_begin, n_q = 4 * 62500, 62500                               # rank 4 of 8
+    idx, dist = knn_graph_device(x.data_ptr(), n, d, k, q_begin=q_begin, n_q=n_q)
+    idx, dist = idx.copy(), dist.copy()
+    host = x.cpu().numpy()
+    picks = np.concatenate([np.random.default_rng(6).choice(n_q, 44, replace=False), [0, 1, 39, 40]])
+    for ql in picks:
+        wi, wd = ko.knn(host, k, q_begin=q_begin + int(ql), n_q=1)
+        assert np.array_equal(idx[ql], wi[0]) and np.array_equal(dist[ql], wd[0])
+    qid = q_begin + np.arange(n_q)
+    assert np.all(idx != qid[:, None]) and np.all(idx >= 0) and np.all(idx < n)
+    assert np.all(np.diff(dist, axis=1) >= 0)
+    ties = np.diff(dist, axis=1) == 0                             # equal distances are ordered by index
+    assert np.all(np.diff(idx, axis=1)[ties] > 0)
+    assert np.all(dist[:40, :39] == 0) and np.all(dist[:40, 39] == 0)   # the 40 duplicates + row 123 see each other at 0
+    again, _ = knn_graph_device(x.data_ptr(), n, d, k, q_begin=q_begin, n_q=n_q)
+    assert np.array_equal(again, idx)
+
+
 def test_config5_fp16_encoder_33k_genes_and_k50(hip, oracle_built):
     # configs[4]: cont encoder at G = 33000 with fp16 MFMA operands, k = 50 kNN
     g, e = 33000, 64

@@ -95,6 +95,34 @@ __device__ __forceinline__ f32x4 lds_read4(const char *p) { return *reinterpret_
                    "v"((b3).x), "v"((b3).y), "v"((b3).z), "v"((b3).w));                                \
   } while (0)
 
+// variant 4: the same bracket with packed FMAs (v_pk_fma_f32: two columns per instruction, the value as an SGPR pair)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#define PKV(v) ((unsigned long long)__builtin_bit_cast(unsigned, (v)) * 0x100000001ull)
+#define FMA16_PK(acc0, acc1, i0, i1, i2, i3, v0, v1, v2, v3, b0, b1, b2, b3)                           \
+  do {                                                                                                 \
+    int m0_save_;                                                                                      \
+    asm volatile("s_mov_b32 %2, m0\n\t"                                                                \
+                 "s_set_gpr_idx_on %3, 0xc\n\t"                                                        \
+                 "v_pk_fma_f32 v[64:65], %7, %11, v[64:65]\n\t"                                        \
+                 "v_pk_fma_f32 v[66:67], %7, %12, v[66:67]\n\t"                                        \
+                 "s_set_gpr_idx_idx %4\n\t"                                                            \
+                 "v_pk_fma_f32 v[64:65], %8, %13, v[64:65]\n\t"                                        \
+                 "v_pk_fma_f32 v[66:67], %8, %14, v[66:67]\n\t"                                        \
+                 "s_set_gpr_idx_idx %5\n\t"                                                            \
+                 "v_pk_fma_f32 v[64:65], %9, %15, v[64:65]\n\t"                                        \
+                 "v_pk_fma_f32 v[66:67], %9, %16, v[66:67]\n\t"                                        \
+                 "s_set_gpr_idx_idx %6\n\t"                                                            \
+                 "v_pk_fma_f32 v[64:65], %10, %17, v[64:65]\n\t"                                       \
+                 "v_pk_fma_f32 v[66:67], %10, %18, v[66:67]\n\t"                                       \
+                 "s_set_gpr_idx_off\n\t"                                                               \
+                 "s_mov_b32 m0, %2\n\t"                                                                \
+                 "s_nop 0"                                                                             \
+                 : "+{v[64:95]}"(acc0), "+{v[96:127]}"(acc1), "=&s"(m0_save_)                          \
+                 : "s"(i0), "s"(i1), "s"(i2), "s"(i3), "s"(PKV(v0)), "s"(PKV(v1)), "s"(PKV(v2)), "s"(PKV(v3)), \
+                   "v"((b0).xy), "v"((b0).zw), "v"((b1).xy), "v"((b1).zw),                             \
+                   "v"((b2).xy), "v"((b2).zw), "v"((b3).xy), "v"((b3).zw));                            \
+  } while (0)
+
 constexpr int ENT_BYTES = 1024;                                  // per wave and stage parity: up to 128 entries
 constexpr int LDS_BYTES = 2 * STAGE_BYTES + 2 * WAVES * ENT_BYTES;  // 160 KiB: the whole LDS of a CU
 
@@ -147,6 +175,10 @@ __global__ __launch_bounds__(THREADS, 1) void spmm_kernel(const Entry *__restric
         int i = 0;
 #ifndef ABL
 #define ABL 0
+#endif
+#if ABL == 5   // variant: packed FMAs in the 4-entry bracket
+#undef FMA16_IDX
+#define FMA16_IDX FMA16_PK
 #endif
 #if ABL == 1 || ABL == 3   // ablation: no FMAs (operands kept alive so the loads are not dead code)
 #undef FMA16_IDX
