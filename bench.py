@@ -27,8 +27,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix
+PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix (= fp32 vector peak)
+PEAK_F16_MFMA_TFLOPS = 2500.0    # dense fp16/bf16 matrix
 PEAK_HBM_GBS = 8000.0
+PCIE_GBS = 63.0                  # host link (spec), bounds the dense-host side numbers
+TRAFFIC_PROFILE = 'r02_pmc_hbm_traffic.json'   # tracked PMC summary that `roofline.traffic` is replayed from
 
 
 def baseline_metric():
@@ -53,7 +56,8 @@ def parse():
                     help='arithmetic of encoder layers 1-2: exact fp32 MFMA (default), fp16 operands, fp16 hi+lo split')
     ap.add_argument('--batch-rows', type=int, default=0, help='rows per pass through the layer stack (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-alt', action='store_true', help='skip the extra f16x2 measurement reported under "alt"')
+    ap.add_argument('--no-alt', action='store_true', help='skip the extra measurements reported under "alt" / "alt_sparse" / "dense_host"')
+    ap.add_argument('--sparse', action='store_true', help='make the sparse first layer (fp32 over the non-zeros) the measured path')
     ap.add_argument('--no-profile', action='store_true', help='diagnostic: no HIP events in the timed region')
     ap.add_argument('--cpu-sample-cells', type=int, default=8192)
     ap.add_argument('--cpu-sample-knn', type=int, default=40000)
@@ -163,7 +167,7 @@ def main():
     # each rank synthesises its own block of rows (same distribution, rank-specific seed); weights are identical
     local, _keep = synth.synth_csr_device(hi - lo, args.genes, density=0.05, seed=1234 + rank)
     enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321,
-                        batch_rows=args.batch_rows or None, dtype=args.dtype)
+                        batch_rows=args.batch_rows or None, dtype=args.dtype, sparse=args.sparse)
     backend = pipeline.HipBackend()
     host_enc_t = torch.empty((hi - lo, args.latent), dtype=torch.float32, pin_memory=True)
     host_enc = host_enc_t.numpy()
@@ -196,48 +200,119 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    def timed_alt(alt_enc):
+        """The same K steps with another encoder object; returns (seconds over all ranks, profile snapshot)."""
+        nonlocal enc
+        enc_main, enc = enc, alt_enc
+        try:
+            step()
+            _lib.profile_enable(True)
+            _lib.profile_reset()
+            fence()
+            t_0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            fence()
+            secs = time.perf_counter() - t_0
+            snap = _lib.profile_snapshot()
+            _lib.profile_enable(False)
+        finally:
+            enc = enc_main
+        if world > 1:
+            tt = torch.tensor([secs], dtype=torch.float64, device=backend.collective_device)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            secs = float(tt.item())
+        return secs, snap
+
     # Same workload once more with layers 1-2 on the fp16 matrix cores (hi+lo split operands,
     # fp32-equivalent: tests/test_gpu_encoder_f16.py holds it to the same 1e-4 tolerance).
     # Reported under "alt"; it never feeds `value`.
-    alt = None
-    if args.dtype == 'f32' and not args.no_alt:
-        enc_main = enc
-        enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321, batch_rows=args.batch_rows or None,
-                            dtype='f16x2')
-        step()
-        _lib.profile_enable(True)
-        _lib.profile_reset()
-        fence()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        fence()
-        alt_elapsed = time.perf_counter() - t0
-        alt_prof = _lib.profile_snapshot()
-        _lib.profile_enable(False)
-        if world > 1:
-            t = torch.tensor([alt_elapsed], dtype=torch.float64, device=backend.collective_device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            alt_elapsed = float(t.item())
+    alt = alt_sparse = None
+    if args.dtype == 'f32' and not args.sparse and not args.no_alt:
+        alt_enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321, batch_rows=args.batch_rows or None,
+                                dtype='f16x2')
+        alt_elapsed, alt_prof = timed_alt(alt_enc)
         a1 = alt_prof['gemm_l1']
+        executed = 2 * a1['work'] / (a1['ms'] * 1e-3) / 1e12 if a1['ms'] > 0 else 0.0
         alt = {'dtype': 'f16x2', 'value': args.cells * args.steps / alt_elapsed, 'unit': 'cells/s',
                'ms_per_step': alt_elapsed / args.steps * 1e3,
-               'layer1_algorithmic_tflops': a1['work'] / (a1['ms'] * 1e-3) / 1e12 if a1['ms'] > 0 else 0.0,
-               'layer1_executed_fp16_tflops': 2 * a1['work'] / (a1['ms'] * 1e-3) / 1e12 if a1['ms'] > 0 else 0.0,
-               'fp16_mfma_peak_tflops': 2500.0, 'fp32_fallback_passes': enc.fp32_fallback_passes(),
+               'layer1_algorithmic_tflops': executed / 2, 'layer1_executed_fp16_tflops': executed,
+               'roofline': {'kernel': 'gemm16_kernel (layer 1, two fp16 products per algorithmic product)', 'bound': 'mfma',
+                            'achieved': executed, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': executed / PEAK_F16_MFMA_TFLOPS, 'traffic': None},
+               'fp32_fallback_passes': alt_enc.fp32_fallback_passes(),
                'note': 'encoder layers 1-2 as v_mfma_f32_32x32x16_f16 on W = W_hi + W_lo (and A = A_hi + A_lo for the '
                        'sigmoid activations), fp32 accumulate; same 1e-4 parity bound as f32; not the headline'}
-        enc = enc_main
+        del alt_enc
+        # ... and with the sparse first layer: exact fp32 FMAs over the non-zeros only (csrc/spmm.hip)
+        sp_enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321, sparse=True)
+        sp_elapsed, sp_prof = timed_alt(sp_enc)
+        s1 = sp_prof['spmm_l1']
+        nz_tflops = s1['work'] / (s1['ms'] * 1e-3) / 1e12 if s1['ms'] > 0 else 0.0
+        alt_sparse = {'dtype': 'f32', 'value': args.cells * args.steps / sp_elapsed, 'unit': 'cells/s',
+                      'ms_per_step': sp_elapsed / args.steps * 1e3,
+                      'roofline': {'kernel': 'spmm_bias_act_kernel<1> (layer 1 over the non-zeros, fp32 vector FMAs)',
+                                   'bound': 'valu', 'achieved': nz_tflops, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': nz_tflops / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                                   'avg_launch_ms': s1['ms'] / max(s1['launches'], 1),
+                                   'flop_per_launch': s1['work'] / max(s1['launches'], 1),
+                                   'dense_equivalent_tflops': (2.0 * (hi - lo) * args.genes * enc.layers[1].units * args.steps
+                                                               / (s1['ms'] * 1e-3) / 1e12) if s1['ms'] > 0 else None},
+                      'stages_rank0': {k: {'launches': v['launches'], 'ms_per_step': v['ms'] / args.steps}
+                                       for k, v in sp_prof.items() if v['launches']},
+                      'note': 'sparse-aware first layer (SURVEY 8 f4): x @ K1 and the raw-input rows of K2 as CSR x dense '
+                              'products over the ~5% non-zeros, fp32 FMA on the vector ALUs; no gather, no dense copy of '
+                              'the counts; same 1e-4 parity bound (tests/test_gpu_sparse.py); opt-in, not the headline'}
+        del sp_enc
+
+    # Side numbers for the reference's actual call shapes (dense host input: BasicBiGan.encoding_prediction gets a
+    # DataFrame, reference src/bigan_basic.py:28-30; keras predict batches of 32, src/__main__.py:44 batch_size 128).
+    dense_host = None
+    if world == 1 and not args.no_alt and args.dtype == 'f32':
+        nd = min(16384, hi - lo)
+        ld = (args.genes + 31) // 32 * 32
+        dense_t = torch.empty((nd, ld), dtype=torch.float32, pin_memory=True)
+        _lib.check(_lib.lib().cc_gather_dense(local.device_handle(), None, 0, nd, ld, dense_t.data_ptr(), 0))
+        pinned = dense_t[:, :args.genes].contiguous().pin_memory()
+        pageable = pinned.numpy().copy()
+
+        def rate(x, reps):
+            enc.predict(x)
+            t_0 = time.perf_counter()
+            for _ in range(reps):
+                enc.predict(x)
+            return len(x) * reps / (time.perf_counter() - t_0)
+
+        def latency_ms(rows):
+            x = pageable[:rows]
+            enc.predict(x)
+            ts = []
+            for _ in range(20):
+                t_0 = time.perf_counter()
+                enc.predict(x)
+                ts.append(time.perf_counter() - t_0)
+            return float(np.median(ts) * 1e3)
+
+        dense_host = {'cells': nd, 'dense_host_cells_per_s': rate(pageable, 2),
+                      'dense_host_pinned_cells_per_s': rate(pinned.numpy(), 2),
+                      'pcie_bound_cells_per_s': PCIE_GBS * 1e9 / (4.0 * args.genes),
+                      'latency_ms_batch32': latency_ms(32), 'latency_ms_batch128': latency_ms(128),
+                      'note': 'cc_encode_dense: fp32 rows from host memory (pageable / pinned), copies of pass i+1 under the '
+                              'kernels of pass i; bounded by the host link (spec 63 GB/s), never part of `value`'}
+        del dense_t, pinned, pageable
 
     if rank == 0:
-        traffic = None   # HBM-side bytes per launch from the PMC passes committed under profiles/
+        traffic = None   # HBM-side bytes per launch, REPLAYED from the PMC passes committed under profiles/
+        dominant = 'spmm_bias_act_kernel<1>' if args.sparse else 'gemm_bias_act_kernel<1>'
         try:
-            kernels = json.load(open(os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')))['kernels']
-            pmc = next(v for k, v in kernels.items() if 'gemm_bias_act_kernel<1>' in k)
-            traffic = (2 * pmc['FETCH_SIZE']['mean_per_launch'] + pmc['WRITE_SIZE']['mean_per_launch']) * 1024
+            kernels = json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_PROFILE)))['kernels']
+            pmc = next(v for k, v in kernels.items() if dominant in k)
+            fetch = pmc['FETCH_SIZE']['mean_per_launch'] if isinstance(pmc['FETCH_SIZE'], dict) else pmc['FETCH_SIZE']
+            write = pmc['WRITE_SIZE']['mean_per_launch'] if isinstance(pmc['WRITE_SIZE'], dict) else pmc['WRITE_SIZE']
+            traffic = (2 * fetch + write) * 1024
         except Exception:
             pass
-        g1 = prof['gemm_l1']
+        g1 = prof['spmm_l1'] if args.sparse else prof['gemm_l1']
         avg_ms = g1['ms'] / max(g1['launches'], 1)
         flop_per_launch = g1['work'] / max(g1['launches'], 1)
         achieved = flop_per_launch / (avg_ms * 1e-3) / 1e12 if avg_ms > 0 else 0.0
@@ -255,15 +330,37 @@ def main():
                        'cells': args.cells, 'genes': args.genes, 'latent': args.latent, 'k': args.k,
                        'arch': args.arch, 'parallelism': f'cells sharded over {world} GPU(s), 1 all-gather/step',
                        'knn_fallback_queries_rank0': int(_lib.lib().cc_knn_last_fallback_count())},
-            'roofline': {'kernel': 'gemm_bias_act_kernel (encoder layer 1, x[B x 30000] @ K1[30000 x 3000])',
-                         'bound': 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                         'traffic_note': 'bytes per 8192-row launch, 2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes (profiles/r01_pmc_hbm_traffic.json); algorithmic minimum 1.45e9',
+            'roofline': {'kernel': ('spmm_bias_act_kernel<1> (encoder layer 1 over the non-zeros of x, fp32 vector FMAs)'
+                                    if args.sparse else
+                                    'gemm_bias_act_kernel<1> (encoder layer 1, x[B x 30000] @ K1[30000 x 3000])'),
+                         'bound': 'valu' if args.sparse else 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
+                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
+                         'traffic_note': f'REPLAYED, not measured in this run: bytes per launch of the dominant kernel, '
+                                         f'2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes of the same command '
+                                         f'(profiles/{TRAFFIC_PROFILE}); algorithmic minimum 1.45e9 for the dense kernel',
                          'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch},
             'stages_rank0': stages,
         }
         if alt is not None:
             line['alt'] = alt
+        if alt_sparse is not None:
+            line['alt_sparse'] = alt_sparse
+        if dense_host is not None:
+            line['dense_host'] = dense_host
+        ksel = [prof[c] for c in ('knn_pack', 'knn_select', 'knn_rerank', 'knn_fallback')]
+        knn_ms = sum(v['ms'] for v in ksel) / args.steps
+        if knn_ms > 0:
+            # algorithmic work of the search: 2 * queries * candidates * d; it runs as three fp16 products
+            # per algorithmic product on the fp16 matrix cores (hi/lo split), plus the float64 re-rank
+            knn_flop = 2.0 * (hi - lo) * args.cells * args.latent
+            ktf = knn_flop / (knn_ms * 1e-3) / 1e12
+            line['roofline_knn'] = {'kernel': 'knn_select16 + knn_collect16 + knn_merge + knn_rerank (per step)',
+                                    'bound': 'mfma', 'achieved': ktf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                    'frac': ktf / PEAK_F16_MFMA_TFLOPS, 'executed_fp16_tflops': 3.375 * ktf,
+                                    'ms_per_step': knn_ms, 'flop_per_step': knn_flop, 'traffic': None,
+                                    'note': 'achieved = algorithmic 2*q*c*d FLOP / stage time; the collect executes 3 fp16 '
+                                            'products per algorithmic one over all candidates and the sample pass 1/8 more '
+                                            '(x3.375); selection (VALU/LDS) shares the time'}
         gather = prof['gather']
         if gather['ms'] > 0:
             gbs = gather['work'] / (gather['ms'] * 1e-3) / 1e9
