@@ -122,8 +122,10 @@ def test_config5_one_ranks_knn_62500_queries_of_500k_k50(hip, oracle_built):
     qid = q_begin + np.arange(n_q)
     assert np.all(idx != qid[:, None]) and np.all(idx >= 0) and np.all(idx < n)
     assert np.all(np.diff(dist, axis=1) >= 0)
-    ties = np.diff(dist, axis=1) == 0                             # equal distances are ordered by index
-    assert np.all(np.diff(idx, axis=1)[ties] > 0)
+    # exact ties are ordered by index (float32 outputs may tie where the float64 distances that decide the order
+    # do not, so the property is checked where the tie is certain: distance 0)
+    zero_ties = (dist[:, 1:] == 0) & (dist[:, :-1] == 0)
+    assert np.all(np.diff(idx, axis=1)[zero_ties] > 0)
     assert np.all(dist[:40, :39] == 0) and np.all(dist[:40, 39] == 0)   # the 40 duplicates + row 123 see each other at 0
     again, _ = knn_graph_device(x.data_ptr(), n, d, k, q_begin=q_begin, n_q=n_q)
     assert np.array_equal(again, idx)
