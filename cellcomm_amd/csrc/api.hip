@@ -204,12 +204,13 @@ static int encoder_pack(Encoder *e) {
     }
   }
   if (e->dtype != CC_DTYPE_F32) {
-    // layers 1-2 again, split into fp16 hi/lo planes for the fp16 matrix cores
+    // layers 1-2 again for the fp16 matrix cores: one plane (f16) or the hi/lo split (f16x2)
+    const int planes16 = e->dtype == CC_DTYPE_F16X2 ? 2 : 1;
     if (e->arch == CC_ARCH_CONT) {
-      if ((rc = pack_weight16(e->w[0].data(), e->w[1].data(), e->G, 0, e->w0, &e->L16[0]))) return rc;
-      if ((rc = pack_weight16(e->w[2].data(), e->w[3].data(), e->w0, e->G, e->w1, &e->L16[1]))) return rc;
+      if ((rc = pack_weight16(e->w[0].data(), e->w[1].data(), e->G, 0, e->w0, planes16, &e->L16[0]))) return rc;
+      if ((rc = pack_weight16(e->w[2].data(), e->w[3].data(), e->w0, e->G, e->w1, planes16, &e->L16[1]))) return rc;
     } else {
-      if ((rc = pack_weight16(e->w[0].data(), e->w[1].data(), e->G, 0, 1000, &e->L16[0]))) return rc;
+      if ((rc = pack_weight16(e->w[0].data(), e->w[1].data(), e->G, 0, 1000, planes16, &e->L16[0]))) return rc;
     }
   }
   e->dirty = false;
@@ -441,7 +442,7 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
     int64_t off = 0;
     for (int64_t i = 0; i < lead; ++i, off += full) plan.push_back({off, full, 0});
     const int64_t rest = n - off, parts = npass - lead;
-    const int64_t each = round_up(ceil_div(rest, parts), GEMM_BM);
+    const int64_t each = round_up(ceil_div(rest, parts), e->dtype == CC_DTYPE_F32 ? GEMM_BM : 256);   // whole m-tiles
     for (int64_t i = 0; off < n; ++i, off += each) plan.push_back({off, (n - off < each) ? n - off : each, (int)(i & 1)});
     if (each > B) B = each;
   } else {
@@ -585,9 +586,9 @@ int cc_encoder_create(int arch, int G, int E, int dtype, void **enc) {
   CC_REQUIRE(G >= 1 && E >= 1, "gene_size=%d and encoding_size=%d must be >= 1", G, E);
   Encoder *e = new Encoder();
   e->arch = arch; e->G = G; e->E = E; e->dtype = dtype;
-  // rows per pass: 8192 rows are exactly 2 + 1 rounds of fp32 tiles (128 x 128, 3 per CU); the fp16 kernels
-  // (256 x 128 tiles, 2 per CU) fill whole rounds with twice that (C3 step 69 -> 65 ms, tools/batch_sweep.sh)
-  e->batch = dtype == CC_DTYPE_F32 ? 8192 : 16384;
+  // rows per pass: 8192 rows are exactly 2 + 1 rounds of fp32 tiles (128 x 128, 3 per CU); the fp16 kernels (256 x 256
+  // tiles, 1 per CU) fill whole rounds with 32768: 1536 tiles = 6 rounds for layer 1, 768 = 3 for layer 2
+  e->batch = dtype == CC_DTYPE_F32 ? 8192 : 32768;
   encoder_shapes(e);
   *enc = e;
   return CC_OK;

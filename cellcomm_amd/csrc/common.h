@@ -114,18 +114,20 @@ int launch_row_softmax(float *X, int64_t M, int E, int64_t ld);
 
 // gemm16.hip — layers 1/2 on the fp16 matrix cores (CC_DTYPE_F16 / CC_DTYPE_F16X2)
 struct PackedWeight16 {
-  void *d_w = nullptr;      // [NT][KT][hi|lo][8][128][8] fp16
-  float *d_bias = nullptr;  // [NT*128]
+  void *d_w = nullptr;      // [NT][KT][plane][TK / 8][256][8] fp16 (plane 0 = hi, plane 1 = lo)
+  float *d_bias = nullptr;  // [NT*256]
   float scale = 1.f;        // power of two applied to W before the fp16 split
+  int planes = 2;           // 1: CC_DTYPE_F16 (K-step 64), 2: CC_DTYPE_F16X2 (K-step 32)
+  int TK = 32;
   int64_t K1 = 0, K2 = 0, KT1 = 0, KT2 = 0, N = 0, NT = 0;
 };
 struct GemmSeg16 {
   const void *A;   // fp16 [M x lda]
-  int64_t lda;     // in halfs, >= KT·64, zero beyond K
+  int64_t lda;     // in halfs, >= KT·TK (a multiple of 64 always suffices), zero beyond K
   int which;       // 0: multiplies weight rows [0,K1), 1: rows [K1,K1+K2)
   int nterms;      // 1: W_hi, 2: W_hi + W_lo
 };
-int pack_weight16(const float *w, const float *bias, int64_t K1, int64_t K2, int64_t N, PackedWeight16 *out);
+int pack_weight16(const float *w, const float *bias, int64_t K1, int64_t K2, int64_t N, int planes, PackedWeight16 *out);
 void free_weight16(PackedWeight16 *w);
 int launch_gemm16(const GemmSeg16 *segs, int nsegs, int64_t M, const PackedWeight16 &W, void *C, void *C_lo,
                   int64_t ldc, int out_fp16, int act, int prof_class);

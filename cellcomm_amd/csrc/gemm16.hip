@@ -1,7 +1,7 @@
-// K2' — encoder layers 1 and 2 on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, fp32 accumulate).
+// K2' — encoder layers 1 and 2 on the fp16 matrix cores (v_mfma_f32_16x16x32_f16, fp32 accumulate).
 //
 // Two uses of one kernel:
-//   CC_DTYPE_F16    operands rounded to fp16 once (BASELINE config 5 "fp16 MFMA"): one term.
+//   CC_DTYPE_F16    operands rounded to fp16 once (BASELINE config 5 "fp16 MFMA"): one term, one weight plane.
 //   CC_DTYPE_F16X2  fp32-equivalent result from fp16 operands: every fp32 weight is split as
 //                   W·s = W_hi + W_lo (two fp16 values, s a power of two so that max|W·s| is in
 //                   [2^13, 2^14)), 22 significant bits; an activation that is not exactly an fp16
@@ -14,56 +14,139 @@
 // "multiply this A tile with W_hi and with W_lo", nterms = 1 "with W_hi only".  A 3-term input is
 // the two segments {A_hi, 2} and {A_lo, 1} over the same weight rows.
 //
-// Tile: 256 x 128 per 256-thread workgroup, 4 waves as 2 x 2, 128 x 64 per wave (128 accumulator
-// registers: the A fragments are re-used by W_hi and W_lo and LDS traffic per MFMA halves against a
-// 64 x 64 wave tile, which is what bound the first version), K-step 64.  LDS: A [256][64+8] fp16 (the pad makes the 16-byte fragment reads
-// conflict-free), W_hi / W_lo tiles [8][128][8] fp16 — pre-packed so a lane's 8 consecutive k for
-// one column are one 16-byte read and a tile is 16 KiB contiguous in HBM.
+// Structure (round 2; prototype and measurements: tools/experiments/gemm16_dma.hip).  256 x 256 tile per 512-thread
+// workgroup, 8 waves as 2 x 4, 128 x 64 per wave = 8 x 4 blocks of 16 x 16 (128 accumulator registers).  Operands
+// reach LDS by LDS-DMA (global_load_lds, 16 bytes per lane, no staging registers), one barrier per K-step, the DMA
+// running 1 (one plane: K-step 64, two 64 KiB stages) or 2 (two planes: K-step 32, three 48 KiB stages) K-steps
+// ahead of the MFMAs.  A rows sit in LDS as 16-byte chunks whose index is XOR-swizzled by the row so that the
+// fragment reads of the 16x16x32 shape are bank-conflict free (the DMA writes linearly, so the swizzle is applied to
+// the per-lane global source address); a weight plane is packed as the linear LDS image [k / 8][256 columns][8 halfs].
+// With two planes the A fragments of a K-step are read once and used against W_hi and W_lo.
+// Measured on layer 1 (16384 x 30016 x 3072, random operands): one plane 1090 TFLOP/s (was 926 with the register-staged
+// 32x32x16 kernel of round 1), two planes 1330 executed (was 1042-1090) = 0.53 of the 2.5 PFLOP/s dense fp16 peak; the
+// 16x16x32 shape alone is worth +13-15 % over 32x32x16 at equal cycles (the chip holds a higher clock on it).
 #include "common.h"
 
 namespace cc {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 
-#ifndef CC_G16_WM
-#define CC_G16_WM 4          // 32-row MFMA tiles per wave along M: 2 -> 128 x 128 workgroup tile, 4 -> 256 x 128
-#endif
-#ifndef CC_G16_MINW
-#define CC_G16_MINW 2
-#endif
-constexpr int WM_T = CC_G16_WM;
-constexpr int HB_M = 64 * WM_T, HB_N = 128, HB_K = 64;
-constexpr int A_PASSES = HB_M / 32;                  // staging passes of 32 rows
-constexpr int H_LDS_A_STRIDE = HB_K + 8;             // halfs
-constexpr int H_THREADS = 256;
-constexpr int H_TILE_W = (HB_K / 8) * HB_N;          // 16-byte units per W tile (1024 = 16 KiB)
+constexpr int H_TM = 256, H_TN = 256, H_THREADS = 512;
+template <int PLANES> struct Cfg16 {
+  static constexpr int TK = PLANES == 1 ? 64 : 32;      // K-step
+  static constexpr int KQ = TK / 32;                    // MFMA k-chunks per K-step
+  static constexpr int CH = TK / 8;                     // 16-byte chunks per A row
+  static constexpr int STAGE_A = H_TM * TK * 2;
+  static constexpr int PLANE_B = TK * H_TN * 2;
+  static constexpr int STAGE = STAGE_A + PLANES * PLANE_B;
+  static constexpr int A_INSTR = STAGE_A / 16 / H_THREADS;   // DMA instructions per thread and K-step for A
+  static constexpr int B_INSTR = PLANE_B / 16 / H_THREADS;   // ... per weight plane
+  static constexpr int NSTAGE = PLANES == 1 ? 2 : 3;
+  static constexpr int LDS = NSTAGE * STAGE;
+};
 
 struct Seg16 {
   const _Float16 *A;   // [M x lda] fp16
   int64_t lda;         // halfs
-  int KT;              // k-tiles of this segment
-  int wkt0;            // first k-tile of the packed weight this segment multiplies
+  int KT;              // K-steps of this segment
+  int wkt0;            // first K-step of the packed weight this segment multiplies
   int nterms;          // 1: W_hi only, 2: W_hi and W_lo
 };
 struct Segs16 { Seg16 s[4]; int n; };
 
 __device__ __forceinline__ float sigmoid16_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
+// Chunk swizzle of an A row in LDS.  A ds_read_b128 is served in groups of 16 lanes; with the 16x16x32 fragment
+// (lane = 16 q + r reads chunk q of row r) a group holds rows {0-3, 12-15} of one k-quarter and rows {4-11} of the
+// next, which must fall on 16 different 16-byte slots of the 256-byte bank row.
+template <int CH> __device__ __forceinline__ int swz16(int row) {
+  if (CH == 4) return (0x78 >> (2 * ((row >> 2) & 3))) & 3;          // {0, 2, 3, 1}[(row >> 2) & 3]
+  const int g = (row >> 1) & 7;
+  return g ^ (((g >> 1) ^ (g >> 2)) & 1);                             // {0, 1, 3, 2, 5, 4, 6, 7}[(row >> 1) & 7]
+}
+
+#define CC_GLDS16(src, dst)                                                                 \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src),   \
+                                   (void __attribute__((address_space(3))) *)(dst), 16, 0, 0)
+
+// One K-segment: the DMA runs NSTAGE - 1 K-steps ahead, one barrier per K-step, everything drained at its end.
+// TWO: the segment multiplies W_lo as well as W_hi.  (A function template with the accumulators passed by reference:
+// as a lambda capturing them hipcc kept part of the state in scratch.)
+template <int PLANES, bool TWO>
+__device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], const _Float16 *(&a_src)[Cfg16<PLANES>::A_INSTR],
+                                               const _Float16 *b_src, int KT, char *smem,
+                                               const int (&a_off)[8][Cfg16<PLANES>::KQ], int b_off, int tid, int wave) {
+  using C_ = Cfg16<PLANES>;
+  constexpr int TK = C_::TK, KQ = C_::KQ, STAGE_A = C_::STAGE_A, PLANE_B = C_::PLANE_B, STAGE = C_::STAGE;
+  constexpr int NSTAGE = C_::NSTAGE;
+  constexpr int NPL = TWO ? 2 : 1;
+  constexpr int DPS = C_::A_INSTR + NPL * C_::B_INSTR;     // DMA instructions per thread and K-step
+  auto issue = [&](int kt, int stage) {
+    char *sa = smem + stage * STAGE, *sb = sa + STAGE_A;
+#pragma unroll
+    for (int i = 0; i < C_::A_INSTR; ++i) CC_GLDS16(a_src[i] + (int64_t)kt * TK, sa + (i * H_THREADS + wave * 64) * 16);
+    const _Float16 *bt = b_src + (int64_t)kt * (PLANES * TK * H_TN);
+#pragma unroll
+    for (int i = 0; i < NPL * C_::B_INSTR; ++i) CC_GLDS16(bt + i * H_THREADS * 8, sb + (i * H_THREADS + wave * 64) * 16);
+  };
+#pragma unroll
+  for (int i = 0; i < NSTAGE - 1; ++i)
+    if (i < KT) issue(i, i);
+  if (KT >= NSTAGE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int stage = 0;
+  for (int kt = 0; kt < KT; ++kt) {
+    // the stage written now was read one K-step ago at the latest, and every wave is past that barrier
+    if (kt + NSTAGE - 1 < KT) issue(kt + NSTAGE - 1, (stage + NSTAGE - 1) % NSTAGE);
+    const char *st = smem + stage * STAGE;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) {
+      h8 a[8], b[NPL][4];
+#pragma unroll
+      for (int mt = 0; mt < 8; ++mt) a[mt] = *reinterpret_cast<const h8 *>(st + a_off[mt][kq]);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          b[p][nt] = *reinterpret_cast<const h8 *>(st + b_off + p * PLANE_B + kq * 16384 + nt * 256);
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int p = 0; p < NPL; ++p)
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[p][nt], acc[mt][nt], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+    // the next K-step's data must have landed; with three stages one more step may stay in flight
+    if (kt + NSTAGE - 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail: fewer steps in flight than the count assumes
+    __syncthreads();
+    stage = (stage + 1) % NSTAGE;
+  }
+}
+
+// PLANES: weight planes in the packed matrix (1: CC_DTYPE_F16, 2: CC_DTYPE_F16X2).
 // OUT_MODE 0: C fp32 [M x ldc];  1: C_hi (and C_lo when split) fp16 planes [M x ldc]
-template <int OUT_MODE>
-__global__ __launch_bounds__(H_THREADS, CC_G16_MINW) void gemm16_kernel(Segs16 segs, int64_t M, const f32x4 *__restrict__ Wp,
+template <int PLANES, int OUT_MODE>
+__global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64_t M, const _Float16 *__restrict__ Wp,
                                                               const float *__restrict__ bias, float inv_scale,
                                                               int KTW, int N, int MT, int NT, void *__restrict__ C,
                                                               void *__restrict__ C_lo, int64_t ldc, int act) {
-  __shared__ __attribute__((aligned(16))) _Float16 lds[HB_M * H_LDS_A_STRIDE + 2 * H_TILE_W * 8];
-  _Float16 *As = lds;
-  f32x4 *Bh = reinterpret_cast<f32x4 *>(lds + HB_M * H_LDS_A_STRIDE);
-  f32x4 *Bl = Bh + H_TILE_W;
+  using C_ = Cfg16<PLANES>;
+  constexpr int TK = C_::TK, KQ = C_::KQ, CH = C_::CH, STAGE_A = C_::STAGE_A, PLANE_B = C_::PLANE_B, STAGE = C_::STAGE;
+  constexpr int NSTAGE = C_::NSTAGE;
+  extern __shared__ __attribute__((aligned(1024))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int r16 = lane & 15, q = lane >> 4;
 
-  const int nwg = MT * NT;
-  const int bid = blockIdx.x;
+  // XCD-aware grouped tile order: blockIdx % 8 = XCD under round-robin dispatch gets a contiguous slab of tiles,
+  // 8 m-tiles share each weight tile consecutively
+  const int nwg = MT * NT, bid = blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
   const int wgid = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
   const int per_group = 8 * NT;
@@ -71,140 +154,62 @@ __global__ __launch_bounds__(H_THREADS, CC_G16_MINW) void gemm16_kernel(Segs16 s
   const int gsz = (MT - first_m < 8) ? MT - first_m : 8;
   const int m_tile = first_m + (wgid % per_group) % gsz;
   const int n_tile = (wgid % per_group) / gsz;
-  const int64_t m0 = (int64_t)m_tile * HB_M;
-  const int n0 = n_tile * HB_N;
+  const int64_t m0 = (int64_t)m_tile * H_TM;
+  const int n0 = n_tile * H_TN;
 
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int r = lane & 31, h = lane >> 5;
+  // per-thread DMA geometry: LDS unit L = i * 512 + tid of the A image is (row L / CH, slot L % CH) and takes the
+  // global chunk slot ^ swz(row) of that row; rows beyond M re-read the last row (their results are not stored).
+  // Units i and i + 1 of a thread are 512 / CH rows apart and share the slot, so one offset serves all of them.
+  constexpr int ROWS_PER_INSTR = H_THREADS / CH;
+  const int a_row0 = tid / CH;
+  const int a_chunk = ((tid % CH) ^ swz16<CH>(a_row0)) << 3;     // swz16 depends on row mod 16 only; ROWS_PER_INSTR % 16 == 0
+  static_assert(ROWS_PER_INSTR % 16 == 0, "swizzle period");
 
-  // A staging: 128 rows x 8 chunks of 16 B; thread -> (row = tid/8 + 32p, chunk = tid%8)
-  const int a_row = tid >> 3, a_ch = tid & 7;
-  int a_lr[A_PASSES];
+  f32x4 acc[8][4];
 #pragma unroll
-  for (int p = 0; p < A_PASSES; ++p) {
-    const int64_t gr = m0 + a_row + 32 * p;
-    a_lr[p] = (int)((gr < M ? gr : M - 1) - m0);
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment addresses inside a stage
+  int a_off[8][KQ];
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int row = wm * 128 + mt * 16 + r16;
+#pragma unroll
+    for (int kq = 0; kq < KQ; ++kq) a_off[mt][kq] = (row * CH + ((4 * kq + q) ^ swz16<CH>(row))) * 16;
   }
-
-  f32x16 acc[WM_T][2];
-#pragma unroll
-  for (int i = 0; i < WM_T; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const f32x4 *Wn = Wp + (int64_t)n_tile * KTW * (2 * H_TILE_W) + tid;   // [n_tile][kt][hi|lo][1024]
-
-  f32x4 ra[A_PASSES], rh[4], rl[4];
-  const _Float16 *a_lds = As + (wm * 32 * WM_T + r) * H_LDS_A_STRIDE + 8 * h;
-  const f32x4 *bh_lds = Bh + h * HB_N + wn * 64 + r;
-  const f32x4 *bl_lds = Bl + h * HB_N + wn * 64 + r;
+  const int b_off = STAGE_A + (q * 256 + wn * 64 + r16) * 16;   // + plane * PLANE_B + kq * 16384 + nt * 256
 
   for (int si = 0; si < segs.n; ++si) {
     const Seg16 sg = segs.s[si];
-    if (sg.KT == 0) continue;
-    const bool two = sg.nterms == 2;   // uniform
-    const _Float16 *pa[A_PASSES];
+    const int KT = sg.KT;
+    if (KT == 0) continue;
+    const _Float16 *a_src[C_::A_INSTR];
 #pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) pa[p] = sg.A + (m0 + a_lr[p]) * sg.lda + 8 * a_ch;
-    const f32x4 *wt = Wn + (int64_t)sg.wkt0 * (2 * H_TILE_W);
+    for (int i = 0; i < C_::A_INSTR; ++i) {
+      const int64_t gr = m0 + a_row0 + i * ROWS_PER_INSTR;
+      a_src[i] = sg.A + (gr < M ? gr : M - 1) * sg.lda + a_chunk;
+    }
+    const _Float16 *b_src = Wp + ((int64_t)n_tile * KTW + sg.wkt0) * (PLANES * TK * H_TN) + tid * 8;
 
-    // prologue of the segment: stage k-tile 0
-    __syncthreads();   // previous segment's last tile fully consumed
-#pragma unroll
-    for (int p = 0; p < A_PASSES; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += HB_K; }
-#pragma unroll
-    for (int p = 0; p < 4; ++p) rh[p] = wt[p * H_THREADS];
-    if (two) {
-#pragma unroll
-      for (int p = 0; p < 4; ++p) rl[p] = wt[H_TILE_W + p * H_THREADS];
-    }
-    wt += 2 * H_TILE_W;
-    {
-      _Float16 *aw = As + a_row * H_LDS_A_STRIDE + 8 * a_ch;
-#pragma unroll
-      for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(aw + p * 32 * H_LDS_A_STRIDE) = ra[p];
-#pragma unroll
-      for (int p = 0; p < 4; ++p) Bh[tid + p * H_THREADS] = rh[p];
-      if (two) {
-#pragma unroll
-        for (int p = 0; p < 4; ++p) Bl[tid + p * H_THREADS] = rl[p];
-      }
-    }
-    __syncthreads();
-
-    for (int kt = 0; kt < sg.KT; ++kt) {
-      const bool more = kt + 1 < sg.KT;
-      if (more) {
-#pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += HB_K; }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) rh[p] = wt[p * H_THREADS];
-        if (two) {
-#pragma unroll
-          for (int p = 0; p < 4; ++p) rl[p] = wt[H_TILE_W + p * H_THREADS];
-        }
-        wt += 2 * H_TILE_W;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int t = 0; t < HB_K / 16; ++t) {
-        h8 a[WM_T], bh[2];
-#pragma unroll
-        for (int mt = 0; mt < WM_T; ++mt)
-          a[mt] = *reinterpret_cast<const h8 *>(a_lds + mt * 32 * H_LDS_A_STRIDE + 16 * t);
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) bh[nt] = __builtin_bit_cast(h8, bh_lds[2 * t * HB_N + nt * 32]);
-#pragma unroll
-        for (int mt = 0; mt < WM_T; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-        if (two) {
-          h8 bl[2];
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) bl[nt] = __builtin_bit_cast(h8, bl_lds[2 * t * HB_N + nt * 32]);
-#pragma unroll
-          for (int mt = 0; mt < WM_T; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-              acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-        }
-      }
-      __builtin_amdgcn_s_setprio(0);
-      __syncthreads();
-      if (more) {
-        _Float16 *aw = As + a_row * H_LDS_A_STRIDE + 8 * a_ch;
-#pragma unroll
-        for (int p = 0; p < A_PASSES; ++p) *reinterpret_cast<f32x4 *>(aw + p * 32 * H_LDS_A_STRIDE) = ra[p];
-#pragma unroll
-        for (int p = 0; p < 4; ++p) Bh[tid + p * H_THREADS] = rh[p];
-        if (two) {
-#pragma unroll
-          for (int p = 0; p < 4; ++p) Bl[tid + p * H_THREADS] = rl[p];
-        }
-      }
-      __syncthreads();
-    }
+    if (PLANES == 2 && sg.nterms == 2) gemm16_segment<PLANES, true>(acc, a_src, b_src, KT, smem, a_off, b_off, tid, wave);
+    else gemm16_segment<PLANES, false>(acc, a_src, b_src, KT, smem, a_off, b_off, tid, wave);
   }
 
-  // epilogue: undo the weight scale, bias, activation
+  // epilogue: undo the weight scale, bias, activation.  Lane (r16, q) holds D[4q + j][r16] of every 16 x 16 block.
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt) {
-    const int col = n0 + wn * 64 + nt * 32 + r;
+  for (int nt = 0; nt < 4; ++nt) {
+    const int col = n0 + wn * 64 + nt * 16 + r16;
     const bool col_ok = col < N;
     const float bcol = col_ok ? bias[col] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < WM_T; ++mt) {
+    for (int mt = 0; mt < 8; ++mt) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * 32 * WM_T + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      for (int j = 0; j < 4; ++j) {
+        const int64_t row = m0 + wm * 128 + mt * 16 + 4 * q + j;
         if (col_ok && row < M) {
-          float z = acc[mt][nt][e] * inv_scale + bcol;
+          float z = acc[mt][nt][j] * inv_scale + bcol;
           z = (act == ACT_SIGMOID) ? sigmoid16_(z) : z;
           if (OUT_MODE == 0) {
             static_cast<float *>(C)[row * ldc + col] = z;
@@ -219,32 +224,38 @@ __global__ __launch_bounds__(H_THREADS, CC_G16_MINW) void gemm16_kernel(Segs16 s
   }
 }
 
-// ---- weight packing: [NT][KT][hi|lo][8][128][8] fp16 ------------------------------------------------
-// 16-byte unit u of a tile = (j = u / 128, i = u % 128) holds k = 8j .. 8j+7 of column i.
+// ---- weight packing: [NT][KT][plane][TK / 8][256][8] fp16 = per (n-tile, K-step, plane) the linear LDS image ------
+// 16-byte unit u of a plane tile = (j = u / 256, i = u % 256) holds k = 8j .. 8j+7 of column i.
+template <int PLANES>
 __global__ void pack_weight16_kernel(const float *__restrict__ w, int64_t K1, int64_t K2, int64_t N, int64_t KT1,
                                      int64_t KT, int64_t NT, float scale, _Float16 *__restrict__ dst) {
-  const int64_t total = NT * KT * (int64_t)H_TILE_W;   // 16-byte units per plane
+  constexpr int TK = Cfg16<PLANES>::TK, UNITS = TK / 8 * H_TN;   // 16-byte units per plane tile
+  const int64_t total = NT * KT * (int64_t)UNITS;
   for (int64_t u = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; u < total; u += (int64_t)gridDim.x * blockDim.x) {
-    const int within = (int)(u % H_TILE_W);
-    const int i = within % HB_N, j = within / HB_N;
-    const int64_t tile = u / H_TILE_W;
+    const int within = (int)(u % UNITS);
+    const int i = within % H_TN, j = within / H_TN;
+    const int64_t tile = u / UNITS;
     const int64_t kt = tile % KT, nt = tile / KT;
-    const int64_t n = nt * HB_N + i;
+    const int64_t n = nt * H_TN + i;
     _Float16 hi[8], lo[8];
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
       int64_t src_row;
       bool ok;
-      if (kt < KT1) { const int64_t k = kt * HB_K + 8 * j + c; ok = k < K1; src_row = k; }
-      else { const int64_t k = (kt - KT1) * HB_K + 8 * j + c; ok = k < K2; src_row = K1 + k; }
+      if (kt < KT1) { const int64_t k = kt * TK + 8 * j + c; ok = k < K1; src_row = k; }
+      else { const int64_t k = (kt - KT1) * TK + 8 * j + c; ok = k < K2; src_row = K1 + k; }
       const float v = (ok && n < N) ? w[src_row * N + n] * scale : 0.f;
       hi[c] = (_Float16)v;
       lo[c] = (_Float16)(v - (float)hi[c]);
     }
-    _Float16 *d_hi = dst + (tile * 2 + 0) * (int64_t)(H_TILE_W * 8) + (int64_t)within * 8;
-    _Float16 *d_lo = dst + (tile * 2 + 1) * (int64_t)(H_TILE_W * 8) + (int64_t)within * 8;
+    _Float16 *d_hi = dst + (tile * PLANES + 0) * (int64_t)(UNITS * 8) + (int64_t)within * 8;
 #pragma unroll
-    for (int c = 0; c < 8; ++c) { d_hi[c] = hi[c]; d_lo[c] = lo[c]; }
+    for (int c = 0; c < 8; ++c) d_hi[c] = hi[c];
+    if (PLANES == 2) {
+      _Float16 *d_lo = dst + (tile * PLANES + 1) * (int64_t)(UNITS * 8) + (int64_t)within * 8;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) d_lo[c] = lo[c];
+    }
   }
 }
 
@@ -254,11 +265,13 @@ void free_weight16(PackedWeight16 *w) {
   *w = PackedWeight16();
 }
 
-int pack_weight16(const float *w, const float *bias, int64_t K1, int64_t K2, int64_t N, PackedWeight16 *out) {
+int pack_weight16(const float *w, const float *bias, int64_t K1, int64_t K2, int64_t N, int planes, PackedWeight16 *out) {
   free_weight16(out);
-  out->K1 = K1; out->K2 = K2; out->N = N;
-  out->KT1 = ceil_div(K1, HB_K); out->KT2 = ceil_div(K2, HB_K);
-  out->NT = ceil_div(N, HB_N);
+  CC_REQUIRE(planes == 1 || planes == 2, "pack_weight16: 1 or 2 planes");
+  const int TK = planes == 1 ? Cfg16<1>::TK : Cfg16<2>::TK;
+  out->K1 = K1; out->K2 = K2; out->N = N; out->planes = planes; out->TK = TK;
+  out->KT1 = ceil_div(K1, TK); out->KT2 = ceil_div(K2, TK);
+  out->NT = ceil_div(N, H_TN);
   const int64_t KT = out->KT1 + out->KT2;
   if (N == 0) return CC_OK;
   // power-of-two scale bringing max|W| into [2^13, 2^14): keeps W_lo out of the fp16 subnormals
@@ -268,25 +281,28 @@ int pack_weight16(const float *w, const float *bias, int64_t K1, int64_t K2, int
   float scale = 1.f;
   if (mx > 0.f && std::isfinite(mx)) { (void)frexpf(mx, &e); scale = ldexpf(1.f, 14 - e); }
   out->scale = scale;
-  const int64_t units = out->NT * KT * (int64_t)H_TILE_W;
-  float *d_raw = nullptr;
+  const int64_t units = out->NT * KT * (int64_t)(TK / 8 * H_TN);
+  DevPtr raw;
   if ((K1 + K2) > 0) {
-    CC_HIP(hipMalloc(&d_raw, sizeof(float) * (size_t)((K1 + K2) * N)));
-    CC_HIP(hipMemcpyAsync(d_raw, w, sizeof(float) * (size_t)((K1 + K2) * N), hipMemcpyHostToDevice, stream()));
+    CC_HIP(raw.alloc(sizeof(float) * (size_t)((K1 + K2) * N)));
+    CC_HIP(hipMemcpyAsync(raw.p, w, sizeof(float) * (size_t)((K1 + K2) * N), hipMemcpyHostToDevice, stream()));
   }
   if (units > 0) {
-    CC_HIP(hipMalloc(&out->d_w, 16 * 2 * (size_t)units));
+    CC_HIP(hipMalloc(&out->d_w, 16 * (size_t)planes * (size_t)units));
     int64_t blocks = ceil_div(units, 256);
     if (blocks > 65536) blocks = 65536;
-    hipLaunchKernelGGL(pack_weight16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_raw, K1, K2, N, out->KT1,
-                       KT, out->NT, scale, static_cast<_Float16 *>(out->d_w));
+    if (planes == 1)
+      hipLaunchKernelGGL(pack_weight16_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, stream(), raw.as<float>(), K1, K2, N,
+                         out->KT1, KT, out->NT, scale, static_cast<_Float16 *>(out->d_w));
+    else
+      hipLaunchKernelGGL(pack_weight16_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, stream(), raw.as<float>(), K1, K2, N,
+                         out->KT1, KT, out->NT, scale, static_cast<_Float16 *>(out->d_w));
     CC_HIP(hipGetLastError());
   }
-  CC_HIP(hipMalloc(&out->d_bias, sizeof(float) * (size_t)(out->NT * HB_N)));
-  CC_HIP(hipMemsetAsync(out->d_bias, 0, sizeof(float) * (size_t)(out->NT * HB_N), stream()));
+  CC_HIP(hipMalloc(&out->d_bias, sizeof(float) * (size_t)(out->NT * H_TN)));
+  CC_HIP(hipMemsetAsync(out->d_bias, 0, sizeof(float) * (size_t)(out->NT * H_TN), stream()));
   CC_HIP(hipMemcpyAsync(out->d_bias, bias, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, stream()));
   CC_HIP(hipStreamSynchronize(stream()));
-  if (d_raw) CC_HIP(hipFree(d_raw));
   return CC_OK;
 }
 
@@ -297,32 +313,39 @@ int launch_gemm16(const GemmSeg16 *segs, int nsegs, int64_t M, const PackedWeigh
   CC_REQUIRE(nsegs >= 1 && nsegs <= 4, "gemm16: 1..4 segments");
   Segs16 sg;
   sg.n = nsegs;
-  double kflops = 0;
   for (int i = 0; i < nsegs; ++i) {
     const GemmSeg16 &g = segs[i];
     const int64_t KT = g.which == 0 ? W.KT1 : W.KT2;
-    CC_REQUIRE(KT == 0 || (g.A && g.lda >= KT * HB_K && g.lda % 8 == 0), "gemm16: segment %d needs lda >= %lld (got %lld)",
-               i, (long long)(KT * HB_K), (long long)g.lda);
-    CC_REQUIRE(g.lda * HB_M < (int64_t)2147483647, "gemm16: lda too large");
+    CC_REQUIRE(g.nterms == 1 || (g.nterms == 2 && W.planes == 2), "gemm16: segment %d asks for %d terms of a %d-plane weight",
+               i, g.nterms, W.planes);
+    CC_REQUIRE(KT == 0 || (g.A && g.lda >= KT * W.TK && g.lda % 8 == 0), "gemm16: segment %d needs lda >= %lld (got %lld)",
+               i, (long long)(KT * W.TK), (long long)g.lda);
     sg.s[i].A = static_cast<const _Float16 *>(g.A);
     sg.s[i].lda = g.lda;
     sg.s[i].KT = (int)KT;
     sg.s[i].wkt0 = g.which == 0 ? 0 : (int)W.KT1;
     sg.s[i].nterms = g.nterms;
   }
-  kflops = (double)(W.K1 + W.K2);
-  const int64_t MT = ceil_div(M, HB_M);
+  const int64_t MT = ceil_div(M, H_TM);
   const int64_t nwg = MT * W.NT;
   CC_REQUIRE(nwg < (int64_t)2147483647, "gemm16: grid too large");
-  ProfScope prof(prof_class, 2.0 * (double)M * kflops * (double)W.N);
-  const f32x4 *wp = reinterpret_cast<const f32x4 *>(W.d_w);
+  static bool attr_done = false;
+  if (!attr_done) {
+    CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<1>::LDS));
+    CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<1>::LDS));
+    CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<2>::LDS));
+    CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<2>::LDS));
+    attr_done = true;
+  }
+  ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
+  const _Float16 *wp = static_cast<const _Float16 *>(W.d_w);
   const int KTW = (int)(W.KT1 + W.KT2);
-  if (out_fp16)
-    hipLaunchKernelGGL(gemm16_kernel<1>, dim3((unsigned)nwg), dim3(H_THREADS), 0, stream(), sg, M, wp, W.d_bias,
-                       1.0f / W.scale, KTW, (int)W.N, (int)MT, (int)W.NT, C, C_lo, ldc, act);
-  else
-    hipLaunchKernelGGL(gemm16_kernel<0>, dim3((unsigned)nwg), dim3(H_THREADS), 0, stream(), sg, M, wp, W.d_bias,
-                       1.0f / W.scale, KTW, (int)W.N, (int)MT, (int)W.NT, C, C_lo, ldc, act);
+#define CC_LAUNCH16(PL, OM)                                                                                          \
+  hipLaunchKernelGGL((gemm16_kernel<PL, OM>), dim3((unsigned)nwg), dim3(H_THREADS), Cfg16<PL>::LDS, stream(), sg, M, \
+                     wp, W.d_bias, 1.0f / W.scale, KTW, (int)W.N, (int)MT, (int)W.NT, C, C_lo, ldc, act)
+  if (W.planes == 1) { if (out_fp16) CC_LAUNCH16(1, 1); else CC_LAUNCH16(1, 0); }
+  else { if (out_fp16) CC_LAUNCH16(2, 1); else CC_LAUNCH16(2, 0); }
+#undef CC_LAUNCH16
   CC_HIP(hipGetLastError());
   return CC_OK;
 }

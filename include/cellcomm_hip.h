@@ -80,7 +80,7 @@ int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols);
  * BatchNormalization contributes gamma, beta, moving_mean, moving_variance).
  * reference src/bigan_cont.py:31-41, src/bigan_classify.py:29-40. */
 int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols);
-/* Rows processed per pass through the layer stack (default 8192 for CC_DTYPE_F32, 16384 for the fp16 dtypes). */
+/* Rows processed per pass through the layer stack (default 8192 for CC_DTYPE_F32, 32768 for the fp16 dtypes). */
 int cc_encoder_set_batch(void *enc, int64_t batch_rows);
 /* Sparse first layer (CC_DTYPE_F32 encoders only, default off).  When on, cc_encode /
  * cc_encode_dev of a CONTIGUOUS row range (row_ids == NULL) never densify the counts: x @ K1 and the raw-input

@@ -16,13 +16,20 @@
 
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int TM = 256, TN = 256, THREADS = 512;
 // TERMS = 1: one fp16 product, K-step 64 (stage = A 32 KiB + B 32 KiB).
 // TERMS = 2: W = W_hi + W_lo (the f16x2 scheme), both planes against the same A fragments, K-step 32
 //            (stage = A 16 KiB + B_hi 16 KiB + B_lo 16 KiB); same MFMAs per barrier, half the LDS reads per MFMA.
+#ifndef G16_TK1
+#define G16_TK1 64     // K-step of the one-term kernel (experiment knob)
+#endif
+#ifndef G16_NST
+#define G16_NST 0      // LDS stages; 0 = 3 if they fit, else 2
+#endif
 template <int TERMS> struct Cfg {
-  static constexpr int TK = 64 / TERMS;
+  static constexpr int TK = TERMS == 1 ? G16_TK1 : 32;
   static constexpr int KC = TK / 16;                    // 16-wide MFMA k-chunks per K-step
   static constexpr int CH = TK / 8;                     // 16-byte chunks per A row
   static constexpr int STAGE_A = TM * TK * 2;
@@ -30,18 +37,26 @@ template <int TERMS> struct Cfg {
   static constexpr int STAGE = STAGE_A + TERMS * PLANE_B;
   static constexpr int A_INSTR = STAGE_A / 16 / THREADS;   // DMA instructions per thread for A
   static constexpr int B_INSTR = PLANE_B / 16 / THREADS;   // ... per plane of B
-  static constexpr int NSTAGE = 3 * STAGE <= 160 * 1024 ? 3 : 2;   // LDS stages (DMA runs NSTAGE-1 K-steps ahead)
+  static constexpr int NSTAGE = (TERMS == 1 && G16_NST) ? G16_NST : (3 * STAGE <= 160 * 1024 ? 3 : 2);   // LDS stages (DMA runs NSTAGE-1 K-steps ahead)
+  static_assert(NSTAGE * STAGE <= 160 * 1024, "stages exceed the LDS");
   static constexpr int DMA_PER_STEP = A_INSTR + TERMS * B_INSTR;
 };
 
 // chunk swizzle of an A row in LDS: 8 consecutive rows must land in 8 different 16-byte slots mod 256 B
 template <int CH> __device__ __forceinline__ int swz(int row) { return CH == 8 ? (row & 7) : ((row ^ (row >> 2)) & 3); }
+// the same for the 16x16x32 shape: a ds_read_b128 lane group there holds rows {0-3, 12-15} of one k-quarter and rows
+// {4-11} of the next, which must land on 16 different 16-byte slots of a 256-byte bank row
+template <int CH> __device__ __forceinline__ int swz16(int row) {
+  if (CH == 4) return (0x78 >> (2 * ((row >> 2) & 3))) & 3;          // {0, 2, 3, 1}[(row >> 2) & 3]
+  const int g = (row >> 1) & 7;
+  return g ^ (((g >> 1) ^ (g >> 2)) & 1);                             // {0, 1, 3, 2, 5, 4, 6, 7}[(row >> 1) & 7]
+}
 
 #define GLDS(src, dst) \
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src), \
                                    (void __attribute__((address_space(3))) *)(dst), 16, 0, 0)
 
-template <int TERMS, bool PIPE>
+template <int TERMS, bool PIPE, bool SHAPE16 = false>
 __global__ __launch_bounds__(THREADS, 1) void gemm16_dma_kernel(const _Float16 *__restrict__ A, int64_t lda,
                                                                 const _Float16 *__restrict__ Wp, int KT, int NT,
                                                                 float *__restrict__ C, int64_t ldc) {
@@ -68,7 +83,7 @@ __global__ __launch_bounds__(THREADS, 1) void gemm16_dma_kernel(const _Float16 *
 #pragma unroll
   for (int i = 0; i < C_::A_INSTR; ++i) {
     const int L = i * THREADS + tid, row = L / CH, s = L % CH;
-    a_src[i] = A + (m0 + row) * lda + ((s ^ swz<CH>(row)) << 3);
+    a_src[i] = A + (m0 + row) * lda + ((s ^ (SHAPE16 ? swz16<CH>(row) : swz<CH>(row))) << 3);
   }
   const _Float16 *b_src = Wp + (int64_t)n_tile * KT * (TERMS * TK * TN) + tid * 8;
 
@@ -80,6 +95,75 @@ __global__ __launch_bounds__(THREADS, 1) void gemm16_dma_kernel(const _Float16 *
 #pragma unroll
     for (int i = 0; i < TERMS * C_::B_INSTR; ++i) GLDS(bt + i * THREADS * 8, sb + (i * THREADS + wave * 64) * 16);
   };
+
+  if constexpr (SHAPE16) {
+    // v_mfma_f32_16x16x32_f16: wave tile 128 x 64 = 8 x 4 blocks of 16 x 16, K = 32 per instruction (16 cycles).
+    // Lane (r = lane & 15, q = lane >> 4) feeds A[row r][k = 8q..8q+7] and B[k = 8q..8q+7][col r]; D[4q + j][r].
+    constexpr int KQ = TK / 32;   // 32-deep k-chunks per K-step
+    const int r16 = lane & 15, q = lane >> 4;
+    f32x4 acc16[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc16[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    constexpr int NSTAGE = C_::NSTAGE;
+    // the DMA runs NSTAGE - 1 K-steps ahead; at a barrier the youngest NSTAGE - 2 steps may still be in flight
+#pragma unroll
+    for (int i = 0; i < NSTAGE - 1; ++i)
+      if (i < KT) issue(i, i);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * C_::DMA_PER_STEP) : "memory");
+    __syncthreads();
+    int a_off[8][KQ];
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt) {
+      const int row = wm * 128 + mt * 16 + r16;
+#pragma unroll
+      for (int kq = 0; kq < KQ; ++kq) a_off[mt][kq] = (row * CH + ((4 * kq + q) ^ swz16<CH>(row))) * 16;
+    }
+    // B image of a plane: [k / 8][256 columns][8 halfs]
+    const int b_off = STAGE_A + (q * 256 + wn * 64 + r16) * 16;   // + plane * PLANE_B + kq * 4 * 256 * 16 + nt * 16 * 16
+    int stage = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+      if (kt + NSTAGE - 1 < KT) issue(kt + NSTAGE - 1, (stage + NSTAGE - 1) % NSTAGE);
+      const char *st = smem + stage * STAGE;
+#pragma unroll
+      for (int kq = 0; kq < KQ; ++kq) {
+        h8 a[8], b[TERMS][4];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) a[mt] = *reinterpret_cast<const h8 *>(st + a_off[mt][kq]);
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+            b[p][nt] = *reinterpret_cast<const h8 *>(st + b_off + p * PLANE_B + kq * 16384 + nt * 256);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int p = 0; p < TERMS; ++p)
+#pragma unroll
+          for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+              acc16[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[p][nt], acc16[mt][nt], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+      if (kt + NSTAGE - 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * C_::DMA_PER_STEP) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail: fewer steps in flight than the count assumes
+      __syncthreads();
+      stage = (stage + 1) % NSTAGE;
+    }
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int col = n_tile * TN + wn * 64 + nt * 16 + r16;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int64_t row = m0 + wm * 128 + mt * 16 + 4 * q + j;
+          C[row * ldc + col] = acc16[mt][nt][j];
+        }
+      }
+    return;
+  }
 
   f32x16 acc[4][2];
 #pragma unroll
@@ -210,7 +294,7 @@ __global__ __launch_bounds__(THREADS, 1) void gemm16_dma_kernel(const _Float16 *
     }
 }
 
-template <int TERMS, bool PIPE>
+template <int TERMS, bool PIPE, bool SHAPE16 = false>
 static int run(int M, int N, int K, const std::vector<_Float16> &hA, const std::vector<float> &hWf) {
   using C_ = Cfg<TERMS>;
   constexpr int TK = C_::TK, KC = C_::KC;
@@ -237,15 +321,15 @@ static int run(int M, int N, int K, const std::vector<_Float16> &hA, const std::
   hipMalloc(&dC, (size_t)M * N * 4);
   hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
   hipMemcpy(dW, hWp.data(), hWp.size() * 2, hipMemcpyHostToDevice);
-  hipFuncSetAttribute(reinterpret_cast<const void *>(gemm16_dma_kernel<TERMS, PIPE>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  hipFuncSetAttribute(reinterpret_cast<const void *>(gemm16_dma_kernel<TERMS, PIPE, SHAPE16>), hipFuncAttributeMaxDynamicSharedMemorySize,
                       C_::NSTAGE * C_::STAGE);
   auto launch = [&]() {
-    hipLaunchKernelGGL((gemm16_dma_kernel<TERMS, PIPE>), dim3(MT * NT), dim3(THREADS), C_::NSTAGE * C_::STAGE, 0, dA, (int64_t)K, dW, KT, NT, dC,
+    hipLaunchKernelGGL((gemm16_dma_kernel<TERMS, PIPE, SHAPE16>), dim3(MT * NT), dim3(THREADS), C_::NSTAGE * C_::STAGE, 0, dA, (int64_t)K, dW, KT, NT, dC,
                        (int64_t)N);
   };
   launch();
   hipDeviceSynchronize();
-  printf("terms=%d pipe=%d launch: %s\n", TERMS, (int)PIPE, hipGetErrorString(hipGetLastError()));
+  printf("terms=%d pipe=%d shape16=%d launch: %s\n", TERMS, (int)PIPE, (int)SHAPE16, hipGetErrorString(hipGetLastError()));
   std::vector<float> hC((size_t)M * N);
   hipMemcpy(hC.data(), dC, hC.size() * 4, hipMemcpyDeviceToHost);
   double worst = 0.0;
@@ -273,7 +357,7 @@ static int run(int M, int N, int K, const std::vector<_Float16> &hA, const std::
   float ms;
   hipEventElapsedTime(&ms, e0, e1);
   ms /= reps;
-  printf("terms=%d pipe=%d M=%d N=%d K=%d: %.3f ms per launch, %.1f TFLOP/s executed fp16 (%.1f algorithmic)\n", TERMS, (int)PIPE, M, N, K, ms,
+  printf("terms=%d pipe=%d shape16=%d M=%d N=%d K=%d: %.3f ms per launch, %.1f TFLOP/s executed fp16 (%.1f algorithmic)\n", TERMS, (int)PIPE, (int)SHAPE16, M, N, K, ms,
          TERMS * 2.0 * M * N * K / (ms * 1e-3) / 1e12, 2.0 * M * N * K / (ms * 1e-3) / 1e12);
   hipFree(dA); hipFree(dW); hipFree(dC);
   return worst < 1e-2 ? 0 : 1;
@@ -287,8 +371,13 @@ int main(int argc, char **argv) {
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (float)((s >> 9) & 0xffff) / 65536.0f; };
   for (auto &v : hA) v = (_Float16)(float)(int)(rnd() * 4.0f);                 // small counts, like the encoder input
   for (auto &v : hWf) v = (rnd() - 0.5f) * 0.03f;
-  int rc = run<1, false>(M, N, K, hA, hWf);
+  int rc = 0;
+#ifndef G16_ONLY16
+  rc |= run<1, false>(M, N, K, hA, hWf);
   rc |= run<2, false>(M, N, K, hA, hWf);
   rc |= run<2, true>(M, N, K, hA, hWf);
+#endif
+  rc |= run<1, false, true>(M, N, K, hA, hWf);
+  rc |= run<2, false, true>(M, N, K, hA, hWf);
   return rc;
 }
