@@ -435,14 +435,16 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   const int64_t npass = ceil_div(n, full);
   int64_t B = n < full ? n : full;
   bool dual = false;
-  if (npass >= 2 && npass <= 8) {
+  // (fp32 kernels only: 3 workgroups per CU leave room for the other stream's tiles; the fp16 kernels take a CU's
+  // whole LDS per workgroup and gain nothing from a second stream — measured 36.4 -> 38.1 ms at C3)
+  if (npass >= 2 && npass <= 8 && e->dtype == CC_DTYPE_F32) {
     dual = true;
     const int64_t lead = npass <= 4 ? 0 : npass - 2;          // full-size passes in front
     lead_passes = lead;
     int64_t off = 0;
     for (int64_t i = 0; i < lead; ++i, off += full) plan.push_back({off, full, 0});
     const int64_t rest = n - off, parts = npass - lead;
-    const int64_t each = round_up(ceil_div(rest, parts), e->dtype == CC_DTYPE_F32 ? GEMM_BM : 256);   // whole m-tiles
+    const int64_t each = round_up(ceil_div(rest, parts), GEMM_BM);
     for (int64_t i = 0; off < n; ++i, off += each) plan.push_back({off, (n - off < each) ? n - off : each, (int)(i & 1)});
     if (each > B) B = each;
   } else {

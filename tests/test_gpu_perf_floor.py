@@ -18,13 +18,14 @@ def test_kernel_rates_stay_above_their_floors(hip):
     enc = cc.HipEncoder(e, g, 'cont', seed=6)
     out = torch.empty((n, e), device='cuda')
     enc.predict_to_device(m, out.data_ptr(), 0, 8192)                     # warm-up: packs weights, allocates workspaces
+    x = torch.rand((100000, 64), device='cuda')
+    torch.cuda.synchronize()
+    knn_graph_device(x.data_ptr(), 100000, 64, 15)                        # ... and the search scratch (cc_shutdown in an earlier test released it)
     _lib.profile_enable(True)
     _lib.profile_reset()
     try:
         for _ in range(3):
             enc.predict_to_device(m, out.data_ptr(), 0, 8192)             # one 8192-row pass: the launch shape of the bench
-        x = torch.rand((100000, 64), device='cuda')
-        torch.cuda.synchronize()
         knn_graph_device(x.data_ptr(), 100000, 64, 15)
         prof = _lib.profile_snapshot()
     finally:
