@@ -41,7 +41,7 @@ def data(n, d, kind):
 
 cases = 0
 while time.time() < t_end:
-    what = rng.choice(['knn_small', 'knn_big', 'encoder', 'shards'], p=[0.45, 0.2, 0.25, 0.1])
+    what = rng.choice(['knn_small', 'knn_big', 'encoder', 'shards', 'sparse', 'dense_host'], p=[0.3, 0.15, 0.2, 0.1, 0.2, 0.05])
     if what == 'knn_small':
         n = int(rng.integers(2, 4000)); d = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 64, 100, 132]))
         k = int(min(rng.choice([1, 2, 7, 15, 40, 100, 128]), n - 1)); inc = bool(rng.integers(0, 2)); kind = str(rng.choice(kinds))
@@ -73,6 +73,33 @@ while time.time() < t_end:
         rel = float(np.max(np.abs(out - truth) / np.abs(truth)))
         ok = rel <= 1e-4 and np.array_equal(enc.predict(m), out)
         desc = (what, arch, g, e, n, dtype, rel)
+    elif what == 'sparse':
+        # sparse first layer: densities from 0.2 % to 60 % (windows of > 128 entries per 16 rows x 64 columns), ragged
+        # shapes, arbitrary contiguous row ranges, non-integer values
+        arch = str(rng.choice(['cont', 'cls'])); g = int(rng.integers(1, 4000)); e = int(rng.integers(1, 70)); n = int(rng.integers(1, 1500))
+        dens = float(10.0 ** rng.uniform(-2.7, -0.2))
+        m = synth.synth_csr(n, g, density=dens, seed=int(rng.integers(1 << 30)))
+        if rng.random() < 0.3:
+            m = cc.CellMatrix(m.indptr, m.indices, (m.values * rng.uniform(0.01, 3.0, len(m.values))).astype(np.float32), g)
+        ws = eo.glorot_weights(arch, e, g, seed=int(rng.integers(1 << 30)), randomize_bn=True, bias_scale=0.2)
+        enc = cc.HipEncoder(e, g, arch, sparse=True)
+        enc.set_weights(ws)
+        out = enc.predict(m)
+        truth = eo.forward(arch, ws, m.to_dense())
+        rel = float(np.max(np.abs(out - truth) / np.abs(truth)))
+        lo = int(rng.integers(0, n)); cnt = int(rng.integers(0, n - lo + 1))
+        part = torch.empty((max(cnt, 1), e), dtype=torch.float32, device='cuda')
+        enc.predict_to_device(m, part.data_ptr(), lo, cnt)
+        ok = rel <= 1e-4 and np.array_equal(enc.predict(m), out) and np.array_equal(part.cpu().numpy()[:cnt], out[lo:lo + cnt])
+        desc = (what, arch, g, e, n, round(dens, 4), rel, lo, cnt)
+    elif what == 'dense_host':
+        g = int(rng.integers(1, 1200)); e = int(rng.integers(1, 40)); n = int(rng.integers(1, 9000))
+        dtype = str(rng.choice(['f32', 'f16x2', 'f16']))
+        m = synth.synth_csr(n, g, density=0.05, seed=int(rng.integers(1 << 30)))
+        enc = cc.HipEncoder(e, g, str(rng.choice(['cont', 'cls'])), seed=int(rng.integers(1 << 30)), dtype=dtype,
+                            batch_rows=int(rng.choice([64, 1000, 2048, 8192])))
+        ok = np.array_equal(enc.predict(m.to_dense()), enc.predict(m))
+        desc = (what, g, e, n, dtype)
     else:
         g = int(rng.integers(50, 2500)); e = int(rng.integers(2, 40)); n = int(rng.integers(50, 3000))
         m = synth.synth_csr(n, g, density=0.05, seed=int(rng.integers(1 << 30)))
