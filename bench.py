@@ -57,6 +57,9 @@ def parse():
     ap.add_argument('--batch-rows', type=int, default=0, help='rows per pass through the layer stack (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true', help='skip the extra measurements reported under "alt" / "alt_sparse" / "dense_host"')
+    ap.add_argument('--dense-host', action='store_true',
+                    help='also measure the dense-host side numbers (cc_encode_dense throughput, batch-32/128 latency); off by '
+                         'default so that the per-kernel averages of a profiled default run are those of the timed passes')
     ap.add_argument('--sparse', action='store_true', help='make the sparse first layer (fp32 over the non-zeros) the measured path')
     ap.add_argument('--no-profile', action='store_true', help='diagnostic: no HIP events in the timed region')
     ap.add_argument('--cpu-sample-cells', type=int, default=8192)
@@ -268,7 +271,7 @@ def main():
     # Side numbers for the reference's actual call shapes (dense host input: BasicBiGan.encoding_prediction gets a
     # DataFrame, reference src/bigan_basic.py:28-30; keras predict batches of 32, src/__main__.py:44 batch_size 128).
     dense_host = None
-    if world == 1 and not args.no_alt and args.dtype == 'f32':
+    if world == 1 and args.dense_host and args.dtype == 'f32':
         nd = min(16384, hi - lo)
         ld = (args.genes + 31) // 32 * 32
         dense_t = torch.empty((nd, ld), dtype=torch.float32, pin_memory=True)
@@ -293,10 +296,15 @@ def main():
                 ts.append(time.perf_counter() - t_0)
             return float(np.median(ts) * 1e3)
 
+        lat32, lat128 = latency_ms(32), latency_ms(128)
+        _lib.check(_lib.lib().cc_encoder_set_low_latency(enc._h, 1))      # split-K form for calls of <= 128 rows
+        lat32_ll, lat128_ll = latency_ms(32), latency_ms(128)
+        _lib.check(_lib.lib().cc_encoder_set_low_latency(enc._h, 0))
         dense_host = {'cells': nd, 'dense_host_cells_per_s': rate(pageable, 2),
                       'dense_host_pinned_cells_per_s': rate(pinned.numpy(), 2),
                       'pcie_bound_cells_per_s': PCIE_GBS * 1e9 / (4.0 * args.genes),
-                      'latency_ms_batch32': latency_ms(32), 'latency_ms_batch128': latency_ms(128),
+                      'latency_ms_batch32': lat32, 'latency_ms_batch128': lat128,
+                      'latency_ms_batch32_low_latency': lat32_ll, 'latency_ms_batch128_low_latency': lat128_ll,
                       'note': 'cc_encode_dense: fp32 rows from host memory (pageable / pinned), copies of pass i+1 under the '
                               'kernels of pass i; bounded by the host link (spec 63 GB/s), never part of `value`'}
         del dense_t, pinned, pageable

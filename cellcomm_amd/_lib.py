@@ -43,6 +43,7 @@ SIGNATURES = {
     'cc_encoder_set_batch': (c_int, [c_void_p, c_int64]),
     'cc_encoder_fp32_fallback_passes': (c_int64, [c_void_p]),
     'cc_encoder_set_sparse_input': (c_int, [c_void_p, c_int]),
+    'cc_encoder_set_low_latency': (c_int, [c_void_p, c_int]),
     'cc_generator_create': (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
     'cc_generator_free': (None, [c_void_p]),
     'cc_generator_num_weights': (c_int, [c_void_p]),

@@ -114,6 +114,7 @@ struct Encoder {
   float *h2_all = nullptr, *h3_all = nullptr, *h4_all = nullptr;
   // sparse first layer (cc_encoder_set_sparse_input): x @ K1 and the raw-input rows of K2 as CSR x dense products
   // on the vector ALUs; the whole call is one pass, so layer 1's output is kept for all rows too
+  bool low_latency = false;        // calls of <= 128 rows: layers 1-2 as split-K (gemm_small.hip)
   bool sparse = false;
   SpmmWeight S1, S2;
   PackedWeight L2a;                // cont: the hidden-activation rows of K2 (+ b2) for the dense MFMA part of layer 2
@@ -373,16 +374,16 @@ static int encoder_forward(Encoder *e, int sl, int64_t M, float *out, float *h2_
   float *h2 = h2_dst ? h2_dst : e->h2[sl];   // h2_dst given (cont arch only): stop after layer 2
   if (e->arch == CC_ARCH_CONT) {
     // reference src/bigan_cont.py:32-41 (Dropout = identity at inference)
-    if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
-    if ((rc = launch_gemm(e->h1[sl], e->ld1, e->x[sl], e->ldx, M, e->L[1], h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1, e->low_latency))) return rc;
+    if ((rc = launch_gemm(e->h1[sl], e->ld1, e->x[sl], e->ldx, M, e->L[1], h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2, e->low_latency))) return rc;
     if (h2_dst) return CC_OK;
     if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], e->h4[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h4[sl], e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   } else {
     // reference src/bigan_classify.py:31-39: p → h → concat[h, p] → 150 → softmax(E)
-    if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
-    if ((rc = launch_gemm(e->h1[sl], e->ld1, nullptr, 0, M, e->L[1], e->h2[sl], e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+    if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1, e->low_latency))) return rc;
+    if ((rc = launch_gemm(e->h1[sl], e->ld1, nullptr, 0, M, e->L[1], e->h2[sl], e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h2[sl], e->ld2, e->h1[sl], e->ld1, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_row_softmax(out, M, e->E, e->E))) return rc;
@@ -559,6 +560,7 @@ int cc_shutdown(void) {
     *ev = nullptr;
   }
   knn_default_ws_release();
+  gemm_small_release();
   (void)hipStreamDestroy(g_stream);
   if (g_stream2) (void)hipStreamDestroy(g_stream2);
   g_stream = g_stream2 = g_cur = nullptr;
@@ -636,6 +638,11 @@ int cc_encoder_set_sparse_input(void *enc, int on) {
   CC_REQUIRE(!on || e->dtype == CC_DTYPE_F32, "the sparse first layer computes in fp32: create the encoder with CC_DTYPE_F32");
   if (e->sparse != (on != 0)) e->dirty = true;   // the panel-packed weights are made at the next pack
   e->sparse = on != 0;
+  return CC_OK;
+}
+
+int cc_encoder_set_low_latency(void *enc, int on) {
+  static_cast<Encoder *>(enc)->low_latency = on != 0;
   return CC_OK;
 }
 

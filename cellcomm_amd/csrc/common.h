@@ -108,9 +108,16 @@ int pack_weight(const float *w, const float *bias, int64_t K1, int64_t K2, int64
 void free_weight(PackedWeight *w);
 // C[M x N] (ldc) = act(A1[M x K1](lda1) @ W[0:K1] + A2[M x K2](lda2) @ W[K1:] + bias)
 // lda* must cover KT*·BK columns and the columns beyond K* must be zero.
+// allow_split_k: calls of <= 128 rows over a long K may take the split-K form of gemm_small.hip (lower latency,
+// same tolerance, but a different summation order than the tiled kernel: opt-in per encoder, cc_encoder_set_low_latency)
 int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M,
-                const PackedWeight &W, float *C, int64_t ldc, int act, int prof_class);
+                const PackedWeight &W, float *C, int64_t ldc, int act, int prof_class, bool allow_split_k = false);
 int launch_row_softmax(float *X, int64_t M, int E, int64_t ld);
+// gemm_small.hip — the same product for M <= 128 rows as split-K over ~1024 workgroups (launch_gemm dispatches to it)
+bool gemm_small_applies(int64_t M, const PackedWeight &W);
+int launch_gemm_small(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M, const PackedWeight &W,
+                      float *C, int64_t ldc, int act, int prof_class);
+void gemm_small_release();
 
 // gemm16.hip — layers 1/2 on the fp16 matrix cores (CC_DTYPE_F16 / CC_DTYPE_F16X2)
 struct PackedWeight16 {

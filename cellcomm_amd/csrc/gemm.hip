@@ -307,7 +307,7 @@ int pack_weight(const float *w, const float *bias, int64_t K1, int64_t K2, int64
 }
 
 int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M,
-                const PackedWeight &W, float *C, int64_t ldc, int act, int prof_class) {
+                const PackedWeight &W, float *C, int64_t ldc, int act, int prof_class, bool allow_split_k) {
   if (M == 0 || W.N == 0) return CC_OK;
   CC_REQUIRE(W.d_bias != nullptr, "gemm: weight not packed");
   CC_REQUIRE(W.KT1 == 0 || (A1 && lda1 >= W.KT1 * BK && lda1 % 4 == 0),
@@ -315,6 +315,8 @@ int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, in
   CC_REQUIRE(W.KT2 == 0 || (A2 && lda2 >= W.KT2 * BK && lda2 % 4 == 0),
              "gemm: segment 2 needs lda >= %lld (got %lld)", (long long)(W.KT2 * BK), (long long)lda2);
   CC_REQUIRE(lda1 * BM < (int64_t)2147483647 && lda2 * BM < (int64_t)2147483647, "gemm: lda too large");
+  // one m-tile over a long K (batches of 32 / 128, the reference's call shapes): split-K form, gemm_small.hip
+  if (allow_split_k && gemm_small_applies(M, W)) return launch_gemm_small(A1, lda1, A2, lda2, M, W, C, ldc, act, prof_class);
   const int64_t MT = ceil_div(M, BM);
   const int64_t nwg = MT * W.NT;
   CC_REQUIRE(nwg < (int64_t)2147483647, "gemm: grid too large");

@@ -137,8 +137,7 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
                                                               int KTW, int N, int MT, int NT, void *__restrict__ C,
                                                               void *__restrict__ C_lo, int64_t ldc, int act) {
   using C_ = Cfg16<PLANES>;
-  constexpr int TK = C_::TK, KQ = C_::KQ, CH = C_::CH, STAGE_A = C_::STAGE_A, PLANE_B = C_::PLANE_B, STAGE = C_::STAGE;
-  constexpr int NSTAGE = C_::NSTAGE;
+  constexpr int TK = C_::TK, KQ = C_::KQ, CH = C_::CH, STAGE_A = C_::STAGE_A;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;

@@ -1,0 +1,137 @@
+// Small-batch form of the Dense layers (M <= 128 rows): the reference's real call shapes are batches of 32 (keras
+// predict, reference src/bigan_basic.py:30) and minibatches of 128 (src/__main__.py:44).  With one m-tile the tiled
+// kernel of gemm.hip has 24 (layer 1) / 12 (layer 2) workgroups, each walking K = 30000 alone: 1.5-3 ms of latency for
+// a layer that only has to stream its weights once (369 MB: ~0.1 ms of HBM time).  Here the K range is split over
+// ~1024 workgroups instead (split-K), every workgroup streams its slice of the SAME packed weight tiles straight
+// from HBM into MFMA operands (no LDS: a B fragment is one coalesced 16-byte load per lane, an A fragment one
+// 16-byte load from the L2-resident activations), and a second small kernel adds the partial sums in a FIXED
+// order (deterministic, bit-reproducible) and applies bias + activation.
+//
+// Arithmetic: v_mfma_f32_32x32x2_f32, exact fp32 as in gemm.hip; the summation order over K differs from the tiled
+// kernel (per split, then over splits), so a row encoded alone and inside a large pass agree to fp32 rounding,
+// not bit for bit — the parity tests hold both to the same 1e-4 against the float64 oracle.
+#include "common.h"
+
+namespace cc {
+
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int SBK = GEMM_BK;                    // k-tile of the packed weights (32)
+constexpr int SBN = GEMM_BN;                    // 128 columns per packed n-tile
+constexpr int S_THREADS = 256;                  // 4 waves, 32 columns each
+constexpr int TILE_W_F4 = (SBK / 4) * SBN;      // float4 per packed W tile
+
+// partial[split][m][n_pad] = A[:, k-range] @ W[k-range, :]   (MS = 32-row blocks of A: 1..4)
+template <int MS>
+__global__ __launch_bounds__(S_THREADS) void gemm_small_partial_kernel(
+    const float *__restrict__ A1, int64_t lda1, const float *__restrict__ A2, int64_t lda2, int M,
+    const f32x4 *__restrict__ Wp, int KT1, int KT, int NT, int nsplit, int kt_per_split, float *__restrict__ partial,
+    int64_t n_pad) {
+  const int n_tile = blockIdx.x % NT, split = blockIdx.x / NT;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int kt0 = split * kt_per_split;
+  const int kt1 = kt0 + kt_per_split < KT ? kt0 + kt_per_split : KT;
+
+  f32x16 acc[MS];
+#pragma unroll
+  for (int i = 0; i < MS; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // rows beyond M re-read row M - 1 (their partial sums are never used)
+  int arow[MS];
+#pragma unroll
+  for (int i = 0; i < MS; ++i) arow[i] = (i * 32 + r) < M ? (i * 32 + r) : M - 1;
+  const f32x4 *wt = Wp + ((int64_t)n_tile * KT + kt0) * TILE_W_F4 + h * SBN + wave * 32 + r;
+
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool seg1 = kt < KT1;                                      // wave-uniform
+    const float *abase = seg1 ? A1 + (int64_t)kt * SBK : A2 + (int64_t)(kt - KT1) * SBK;
+    const int64_t lda = seg1 ? lda1 : lda2;
+    f32x4 b[4], a[MS][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b[t] = wt[2 * t * SBN];              // k = 8t + 4h .. +3 of this lane's column
+#pragma unroll
+    for (int i = 0; i < MS; ++i)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[i][t] = *reinterpret_cast<const f32x4 *>(abase + arow[i] * lda + 8 * t + 4 * h);
+    wt += TILE_W_F4;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int i = 0; i < MS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t][u], b[t][u], acc[i], 0, 0, 0);
+  }
+
+  float *dst = partial + (int64_t)split * (MS * 32) * n_pad + n_tile * SBN + wave * 32 + r;
+#pragma unroll
+  for (int i = 0; i < MS; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int row = i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      dst[(int64_t)row * n_pad] = acc[i][e];
+    }
+}
+
+// C[m][n] = act(bias[n] + sum over splits in order 0, 1, 2, ... of partial[split][m][n])
+__global__ void gemm_small_reduce_kernel(const float *__restrict__ partial, int nsplit, int m_pad, int64_t n_pad, int M,
+                                         int N, const float *__restrict__ bias, float *__restrict__ C, int64_t ldc,
+                                         int act) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (int64_t)M * N) return;
+  const int m = (int)(t / N), n = (int)(t % N);
+  float z = 0.f;
+  for (int s = 0; s < nsplit; ++s) z += partial[((int64_t)s * m_pad + m) * n_pad + n];
+  z += bias[n];
+  C[(int64_t)m * ldc + n] = act == ACT_SIGMOID ? 1.0f / (1.0f + expf(-z)) : (act == ACT_RELU ? fmaxf(z, 0.f) : z);
+}
+
+DevBuf g_partial;   // split-K partial sums; released by gemm_small_release (cc_shutdown)
+
+}  // namespace
+
+void gemm_small_release() { g_partial.release(); }
+
+bool gemm_small_applies(int64_t M, const PackedWeight &W) {
+  // worth it when the tiled kernel would run a single m-tile over a long K; the tail layers (K <= 1650) stay tiled
+  return M >= 1 && M <= 128 && W.N > 0 && (W.KT1 + W.KT2) >= 64;
+}
+
+int launch_gemm_small(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M, const PackedWeight &W,
+                      float *C, int64_t ldc, int act, int prof_class) {
+  const int KT = (int)(W.KT1 + W.KT2), NT = (int)W.NT;
+  const int MS = (int)ceil_div(M, 32), m_pad = MS * 32;
+  const int64_t n_pad = (int64_t)NT * SBN;
+  // ~1024 workgroups, at least 8 k-tiles each
+  int nsplit = (int)ceil_div(1024, NT);
+  if (nsplit > KT / 8) nsplit = KT / 8 > 0 ? KT / 8 : 1;
+  const int kt_per_split = (int)ceil_div(KT, nsplit);
+  nsplit = (int)ceil_div(KT, kt_per_split);
+  int rc;
+  if ((rc = g_partial.alloc(sizeof(float) * (size_t)nsplit * (size_t)m_pad * (size_t)n_pad))) return rc;
+  ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
+  const f32x4 *wp = reinterpret_cast<const f32x4 *>(W.d_w);
+#define CC_SMALL(MSV)                                                                                              \
+  hipLaunchKernelGGL(gemm_small_partial_kernel<MSV>, dim3((unsigned)(NT * nsplit)), dim3(S_THREADS), 0, stream(), A1, \
+                     lda1, A2, lda2, (int)M, wp, (int)W.KT1, KT, NT, nsplit, kt_per_split, g_partial.as<float>(), n_pad)
+  switch (MS) {
+    case 1: CC_SMALL(1); break;
+    case 2: CC_SMALL(2); break;
+    case 3: CC_SMALL(3); break;
+    default: CC_SMALL(4); break;
+  }
+#undef CC_SMALL
+  CC_HIP(hipGetLastError());
+  const int64_t total = M * W.N;
+  hipLaunchKernelGGL(gemm_small_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
+                     g_partial.as<float>(), nsplit, m_pad, n_pad, (int)M, (int)W.N, W.d_bias, C, ldc, act);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+}  // namespace cc

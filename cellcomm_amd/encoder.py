@@ -74,7 +74,8 @@ def _layer_plan(arch, encoding_size, gene_size):
 class HipEncoder:
     name = 'cell_encoder'
 
-    def __init__(self, encoding_size, gene_size, arch=ARCH_CONT, seed=None, batch_rows=None, dtype='f32', sparse=False):
+    def __init__(self, encoding_size, gene_size, arch=ARCH_CONT, seed=None, batch_rows=None, dtype='f32', sparse=False,
+                 low_latency=False):
         if arch not in _ARCH_CODE:
             raise ValueError(f'unknown encoder arch {arch!r}')
         if dtype not in _DTYPE_CODE:
@@ -99,6 +100,12 @@ class HipEncoder:
             if dtype != 'f32':
                 raise ValueError('sparse=True computes in fp32: use dtype="f32"')
             _lib.check(lib.cc_encoder_set_sparse_input(self._h, 1))
+        # low_latency=True: calls of <= 128 rows (keras predict batches of 32, minibatches of 128) run the two big
+        # fp32 layers split-K over the whole chip; results stay within the same tolerance and are reproducible, but
+        # are no longer bit-identical to the same rows inside a larger call
+        self.low_latency = bool(low_latency)
+        if self.low_latency:
+            _lib.check(lib.cc_encoder_set_low_latency(self._h, 1))
         self._shapes = []
         for i in range(lib.cc_encoder_num_weights(self._h)):
             r, c = ctypes.c_int64(), ctypes.c_int64()
