@@ -112,6 +112,31 @@ def test_forced_fallback_agrees(hip, oracle_built):
     assert hipknn.last_fallback_count() < 1800
 
 
+@pytest.mark.parametrize('n_q,k', [(1, 15), (3, 50), (40, 128), (300, 15)])
+def test_few_uncertified_queries_scan_in_parallel(hip, oracle_built, n_q, k):
+    """A query without a usable prefilter list scans every candidate in float64; a handful of such queries are split
+    over candidate ranges (one workgroup walking 500k candidates alone cost 6.4 ms) and merged.  Forced here with the
+    fallback hook and the prefilter off on a small query range; duplicates sit across range boundaries."""
+    import torch
+    rng = np.random.default_rng(n_q + k)
+    n, d = 60000, 24
+    x = rng.random((n, d), dtype=np.float32)
+    x[4090:4100] = x[20000]                                  # exact ties on both sides of a 4096-candidate boundary
+    x[59990:] = x[20001]
+    q0 = 19990
+    t = torch.from_numpy(x).cuda()
+    hipknn.force_fallback(True)
+    hipknn.use_fp64_prefilter(False)
+    try:
+        idx, dist = hipknn.knn_graph_device(t.data_ptr(), n, d, k, q_begin=q0, n_q=n_q)
+        assert hipknn.last_fallback_count() == n_q and hipknn.last_full_scan_count() == n_q
+    finally:
+        hipknn.force_fallback(False)
+        hipknn.use_fp64_prefilter(True)
+    want_i, want_d = ko.knn(x, k, q_begin=q0, n_q=n_q)
+    assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d)
+
+
 def test_near_ties_below_fp32_resolution(hip, oracle_built):
     # neighbours whose distances differ by far less than the fp32 error of stage 1
     rng = np.random.default_rng(6)
