@@ -285,11 +285,12 @@ int pack_weight(const float *w, const float *bias, int64_t K1, int64_t K2, int64
   const int64_t KT = out->KT1 + out->KT2;
   if (N == 0) return CC_OK;
   const int64_t packed = out->NT * KT * (int64_t)TILE_W_FLOAT4 * 4;
-  float *d_raw = nullptr;
+  DevPtr raw;   // staging copy of the host weights, released on every return path
   if ((K1 + K2) > 0) {
-    CC_HIP(hipMalloc(&d_raw, sizeof(float) * (size_t)((K1 + K2) * N)));
-    CC_HIP(hipMemcpyAsync(d_raw, w, sizeof(float) * (size_t)((K1 + K2) * N), hipMemcpyHostToDevice, stream()));
+    CC_HIP(raw.alloc(sizeof(float) * (size_t)((K1 + K2) * N)));
+    CC_HIP(hipMemcpyAsync(raw.p, w, sizeof(float) * (size_t)((K1 + K2) * N), hipMemcpyHostToDevice, stream()));
   }
+  const float *d_raw = raw.as<float>();
   if (packed > 0) {
     CC_HIP(hipMalloc(&out->d_w, sizeof(float) * (size_t)packed));
     int64_t blocks = ceil_div(packed, 256);
@@ -302,7 +303,6 @@ int pack_weight(const float *w, const float *bias, int64_t K1, int64_t K2, int64
   CC_HIP(hipMemsetAsync(out->d_bias, 0, sizeof(float) * (size_t)(out->NT * BN), stream()));
   CC_HIP(hipMemcpyAsync(out->d_bias, bias, sizeof(float) * (size_t)N, hipMemcpyHostToDevice, stream()));
   CC_HIP(hipStreamSynchronize(stream()));
-  if (d_raw) CC_HIP(hipFree(d_raw));
   return CC_OK;
 }
 
