@@ -101,24 +101,42 @@ __device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], const _Float1
     // the stage written now was read one K-step ago at the latest, and every wave is past that barrier
     if (kt + NSTAGE - 1 < KT) issue(kt + NSTAGE - 1, (stage + NSTAGE - 1) % NSTAGE);
     const char *st = smem + stage * STAGE;
+    // A K-step is consumed in half-chunks (k-chunk kq, row half hf: 4 of the wave's 8 row blocks = 16 or 32 MFMAs).  The
+    // fragments of half-chunk i+1 are read from LDS BEFORE the MFMAs of half-chunk i are issued, so only the first
+    // read of a K-step (right behind the barrier) is exposed; the B fragments of a k-chunk serve both halves.
+    constexpr int NH = 2 * KQ;
+    h8 a[2][4], b[KQ > 1 ? 2 : 1][NPL][4];
+    auto load_a = [&](int kq, int hf, h8 (&dst)[4]) {
 #pragma unroll
-    for (int kq = 0; kq < KQ; ++kq) {
-      h8 a[8], b[NPL][4];
-#pragma unroll
-      for (int mt = 0; mt < 8; ++mt) a[mt] = *reinterpret_cast<const h8 *>(st + a_off[mt][kq]);
+      for (int mt = 0; mt < 4; ++mt) dst[mt] = *reinterpret_cast<const h8 *>(st + a_off[4 * hf + mt][kq]);
+    };
+    auto load_b = [&](int kq, h8 (&dst)[NPL][4]) {
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-          b[p][nt] = *reinterpret_cast<const h8 *>(st + b_off + p * PLANE_B + kq * 16384 + nt * 256);
+          dst[p][nt] = *reinterpret_cast<const h8 *>(st + b_off + p * PLANE_B + kq * 16384 + nt * 256);
+    };
+    load_b(0, b[0]);
+    load_a(0, 0, a[0]);
+#pragma unroll
+    for (int hc = 0; hc < NH; ++hc) {
+      const int kq = hc >> 1, hf = hc & 1;
+      if (hc + 1 < NH) {
+        const int nkq = (hc + 1) >> 1, nhf = (hc + 1) & 1;
+        if (nhf == 0) load_b(nkq, b[nkq & 1]);
+        load_a(nkq, nhf, a[(hc + 1) & 1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int p = 0; p < NPL; ++p)
 #pragma unroll
-        for (int mt = 0; mt < 8; ++mt)
+        for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 4; ++nt)
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[mt], b[p][nt], acc[mt][nt], 0, 0, 0);
+            acc[4 * hf + mt][nt] =
+                __builtin_amdgcn_mfma_f32_16x16x32_f16(a[hc & 1][mt], b[KQ > 1 ? (kq & 1) : 0][p][nt], acc[4 * hf + mt][nt], 0, 0, 0);
       __builtin_amdgcn_s_setprio(0);
     }
     // the next K-step's data must have landed; with three stages one more step may stay in flight
