@@ -282,7 +282,6 @@ static int encoder_ensure_all_rows(Encoder *e, int64_t n, bool with_h1) {
 // src/bigan_cont.py:32-41, src/bigan_classify.py:31-39; see spmm.hip).
 static int encode_csr_sparse(Encoder *e, Csr *c, int64_t row_start, int64_t n, float *dev_out) {
   int rc;
-  if (!c->stream.d_offs && (rc = build_spmm_stream(c->indptr, c->indices, c->vals, c->n_rows, c->G, &c->stream))) return rc;
   e->ldx = pad32(e->G); e->ld1 = pad32(e->w0); e->ld2 = pad32(e->w1); e->ld3 = pad32(150);
   if ((rc = encoder_ensure_all_rows(e, n, true))) return rc;
   const double nnz_hint = c->n_rows ? (double)c->nnz / (double)c->n_rows * (double)n : 0.0;
@@ -420,8 +419,12 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   if (n == 0) return CC_OK;
   // contiguous rows of a matrix through the sparse first layer; sampled rows (minibatches) and degenerate widths
   // (int(G*0.1) == 0) keep the gather + dense path
-  if (e->sparse && e->dtype == CC_DTYPE_F32 && !row_ids && e->w0 > 0 && e->w1 > 0)
-    return encode_csr_sparse(e, c, row_start, n, dev_out);
+  if (e->sparse && e->dtype == CC_DTYPE_F32 && !row_ids && e->w0 > 0 && e->w1 > 0) {
+    if (!c->stream.d_offs && !c->stream.unusable &&
+        (rc = build_spmm_stream(c->indptr, c->indices, c->vals, c->n_rows, c->G, &c->stream)))
+      return rc;
+    if (!c->stream.unusable) return encode_csr_sparse(e, c, row_start, n, dev_out);
+  }
   // Pass plan.  GEMM time is quantised in rounds of 768 resident tiles, so a short pass leaves most
   // CUs idle in its final round.  Calls of 2-4 passes (the per-rank shards at 4 and 8 GPUs) are cut
   // into equal passes that alternate between two streams with their own workspaces: the idle CUs of

@@ -160,6 +160,7 @@ struct SpmmStream {           // the matrix's non-zeros re-ordered per 16-row gr
   int *d_offs = nullptr;      // [ngroups][nstages + 1] stream index of each (group, stage); bit 0 = padded
   int64_t n_rows = 0, n_entries = 0, ngroups = 0;
   int G = 0, nstages = 0;
+  bool unusable = false;      // the matrix does not fit the 32-bit stream offsets: dense path only
 };
 // w_rows: [K x N] row-major host weights (rows that multiply the raw counts), bias: [N] or NULL
 int pack_spmm_weight(const float *w_rows, const float *bias, int64_t K, int64_t N, SpmmWeight *out);
