@@ -785,21 +785,18 @@ __global__ __launch_bounds__(64, 3) void knn_select16_kernel(
   }
 }
 
-// PRE: the hi fragments of this block are already in `ah_in` (read one block ahead by the caller); the lo fragments
-// are read here, in front of the 2·ND + 1 MFMAs that do not need them.
-template <int ND, bool PRE>
-__device__ __forceinline__ void collect16_step(const h8 *__restrict__ sb, const h8 (&ah_in)[ND + 1], const h8 (&bqh)[ND + 1],
-                                               const h8 (&bql)[ND], int64_t b, int64_t NB, int64_t self_blk, int self_e,
-                                               unsigned tail_vm, float Ts, float inv_s2, WaveBuf &wb,
-                                               u64 *__restrict__ buf, int *__restrict__ cursor, int64_t q0, int64_t n_q,
-                                               int cap, int lane) {
+template <int ND>
+__device__ __forceinline__ void collect16_step(const h8 *__restrict__ sb, const h8 (&bqh)[ND + 1], const h8 (&bql)[ND],
+                                               int64_t b, int64_t NB, int64_t self_blk, int self_e, unsigned tail_vm,
+                                               float Ts, float inv_s2, WaveBuf &wb, u64 *__restrict__ buf,
+                                               int *__restrict__ cursor, int64_t q0, int64_t n_q, int cap, int lane) {
   const int r = lane & 31, h = lane >> 5;
   f32x16 acc;
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[e] = 0.f;
   h8 ah[ND + 1], al[ND];
 #pragma unroll
-  for (int t = 0; t <= ND; ++t) ah[t] = PRE ? ah_in[t] : sb[t * 64 + lane];
+  for (int t = 0; t <= ND; ++t) ah[t] = sb[t * 64 + lane];
 #pragma unroll
   for (int t = 0; t < ND; ++t) al[t] = sb[(ND + 1 + t) * 64 + lane];
 #pragma unroll
@@ -817,9 +814,6 @@ __device__ __forceinline__ void collect16_step(const h8 *__restrict__ sb, const 
   }
   park_passes(acc, Ts, inv_s2, (unsigned)(b * 32) + 4 * h, r, wb, buf, cursor, q0, n_q, cap, lane);
 }
-#ifndef CC_KNN_C16_PREFETCH
-#define CC_KNN_C16_PREFETCH 0   // read a block's hi fragments while the previous block of the stage is in the matrix pipes
-#endif
 #ifndef CC_KNN_C16_MINW
 #define CC_KNN_C16_MINW 3
 #endif
@@ -912,31 +906,13 @@ __global__ __launch_bounds__(256, CC_KNN_C16_MINW) void knn_collect16_kernel(
       }
     }
     const h8 *sbuf = stage + cur * STAGE_U;
-#if CC_KNN_C16_PREFETCH
-    h8 ahp[2][ND + 1];
-#pragma unroll
-    for (int t = 0; t <= ND; ++t) ahp[0][t] = sbuf[t * 64 + lane];
-#pragma unroll
-    for (int cb = 0; cb < C16_CB; ++cb) {
-      const int64_t b = b_lo + st * C16_CB + cb;
-      if (cb + 1 < C16_CB) {
-#pragma unroll
-        for (int t = 0; t <= ND; ++t) ahp[(cb + 1) & 1][t] = sbuf[(cb + 1) * BLK_U + t * 64 + lane];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if (b < b_hi)
-        collect16_step<ND, true>(sbuf + cb * BLK_U, ahp[cb & 1], bqh, bql, b, NB, self_blk, self_e, tail_vm, Ts, inv_s2, wb,
-                                 buf, cursor, q0, n_q, cap, lane);
-    }
-#else
 #pragma unroll
     for (int cb = 0; cb < C16_CB; ++cb) {
       const int64_t b = b_lo + st * C16_CB + cb;
       if (b < b_hi)
-        collect16_step<ND, false>(sbuf + cb * BLK_U, bqh, bqh, bql, b, NB, self_blk, self_e, tail_vm, Ts, inv_s2, wb, buf,
-                                  cursor, q0, n_q, cap, lane);
+        collect16_step<ND>(sbuf + cb * BLK_U, bqh, bql, b, NB, self_blk, self_e, tail_vm, Ts, inv_s2, wb, buf, cursor, q0,
+                           n_q, cap, lane);
     }
-#endif
     if (more) {
       f32x4 *dbuf = stage_v + (cur ^ 1) * STAGE_U;
 #pragma unroll
