@@ -32,8 +32,9 @@ def get_file_name(full_path):
 
 
 def check_files(sources):
-    for src in sources:
-        assert os.path.exists(src), f'File not found: {src}'
+    missing = [src for src in sources if not os.path.exists(src)]
+    if missing:
+        raise AssertionError(f'File not found: {missing[0]}')
 
 
 def _matches(doc, query):
@@ -101,70 +102,80 @@ class MemoryDatabase:
                     f.write(json.dumps(doc, default=lambda o: o.isoformat() if isinstance(o, datetime) else str(o)) + '\n')
 
 
+def _require(condition, message):
+    """The reference signals misuse with `assert` (AssertionError + message); same type and text here, also under -O."""
+    if not condition:
+        raise AssertionError(message)
+
+
+class _IterationWriter:
+    """The `(it, losses)` interceptor of one recorder: encodes the trainer's whole data set, stores the iteration's
+    `encits` document and moves the run document's `defit` / `showits` along."""
+
+    def __init__(self, owner, trainer, dims, knn_k):
+        self.owner, self.trainer, self.dims, self.knn_k = owner, trainer, dims, knn_k
+        self.shown = []
+
+    def __call__(self, it, _losses):
+        rec = self.owner
+        _require(it not in rec._seen_iterations, f'duplicate iteration {it}')
+        rec._seen_iterations.append(it)
+        encodings = self.trainer.network.encoding_prediction(self.trainer.data)
+        graph = None
+        if self.knn_k is not None:
+            from .knn import knn_graph
+            graph = knn_graph(np.ascontiguousarray(encodings, dtype=np.float32), self.knn_k)
+        if self.dims is None:
+            document = schema.encits_document(rec.enc_run_id, it, encodings, rec.barcodes, knn=graph)
+        else:
+            document = schema.encits_from_wide(rec.enc_run_id, it, encodings, rec.barcodes, dims=self.dims, knn=graph)
+        document['cids'] = rec.cell_ids
+        rec._collection(ITERATIONS_COLLECTION).insert_one(document)
+        self.shown.append(it)
+        rec._collection(ENCODINGS_COLLECTION).update_one({'_id': rec.enc_run_id},
+                                                         {'$set': {'defit': it, 'showits': list(self.shown)}})
+
+
 class DbRecorder:
+    """`DbRecorder(enc_run_id, sources, m_db)`; `sources` = {'matrix', 'barcodes', 'genes'} file paths."""
+
     def __init__(self, enc_run_id, sources, m_db=None):
         self.enc_run_id = enc_run_id
-        self.matrix_file = sources['matrix']
-        self.barcodes_file = sources['barcodes']
-        self.genes_file = sources['genes']
+        self.matrix_file, self.barcodes_file, self.genes_file = (sources[k] for k in ('matrix', 'barcodes', 'genes'))
         check_files([self.matrix_file, self.barcodes_file, self.genes_file])
-        self.mongo_db = m_db if m_db is not None else MemoryDatabase()
-        self.source_id = None
-        self.barcodes = None
-        self.cell_ids = None
-        self.__processed_its = []
+        self.mongo_db = MemoryDatabase() if m_db is None else m_db
+        self.source_id = self.barcodes = self.cell_ids = None
+        self._seen_iterations = []
+
+    def _collection(self, name):
+        return self.mongo_db[name]
 
     def setup(self):
         self.store_encoding_run()
         self.load_barcodes()
 
-    def __coll(self, coll_name):
-        return self.mongo_db[coll_name]
-
     def store_encoding_run(self, now=None):
-        assert self.__coll(ENCODINGS_COLLECTION).find_one({'_id': self.enc_run_id}) is None, \
-            f'Encoding run id already exists: {self.enc_run_id}'
+        runs = self._collection(ENCODINGS_COLLECTION)
+        _require(runs.find_one({'_id': self.enc_run_id}) is None, f'Encoding run id already exists: {self.enc_run_id}')
         self.source_id = get_file_name(self.barcodes_file)
-        self.__coll(ENCODINGS_COLLECTION).insert_one(schema.encs_run_document(
-            self.enc_run_id, {'matrix': self.matrix_file, 'barcodes': self.barcodes_file, 'genes': self.genes_file}, now))
+        paths = {'matrix': self.matrix_file, 'barcodes': self.barcodes_file, 'genes': self.genes_file}
+        runs.insert_one(schema.encs_run_document(self.enc_run_id, paths, now))
 
     def load_barcodes(self):
-        assert self.source_id, 'Cannot load barcodes without encoding!'
-        cells = self.__coll(CELLS_COLLECTION)
-        query = {'sid': self.source_id}
-        if cells.count_documents(query) == 0:
-            cell_docs, gene_docs = schema.cells_and_genes_documents(self.source_id, self.matrix_file,
-                                                                    self.barcodes_file, self.genes_file)
+        _require(self.source_id, 'Cannot load barcodes without encoding!')
+        cells = self._collection(CELLS_COLLECTION)
+        by_source = {'sid': self.source_id}
+        if cells.count_documents(by_source) == 0:      # first run on this source: import its cells / genes documents
+            cell_docs, gene_docs = schema.cells_and_genes_documents(self.source_id, self.matrix_file, self.barcodes_file,
+                                                                    self.genes_file)
             cells.insert_many(cell_docs)
-            self.__coll(GENES_COLLECTION).insert_many(gene_docs)
-        self.barcodes = [cell['n'] for cell in cells.find(query, {'_id': 0, 'n': 1})]
-        self.cell_ids = [schema.cell_id_from(i) for i in range(len(self.barcodes))]
+            self._collection(GENES_COLLECTION).insert_many(gene_docs)
+        self.barcodes = [doc['n'] for doc in cells.find(by_source, {'_id': 0, 'n': 1})]
+        self.cell_ids = [schema.cell_id_from(pos) for pos in range(len(self.barcodes))]
 
     def create_interceptor(self, trainer, dims=None, knn_k=None):
         """`dims=None` is the reference: the encodings must be N x 3.  `dims=(a, b, c)` exports those three
         latent dimensions of wider encodings (E = 32/64; `schema.encits_from_wide`).  `knn_k` attaches the exact
         kNN graph of the FULL-width encodings as the additive `nn` / `nd` fields."""
-        assert self.barcodes, 'Cannot store iterations without barcodes!'
-        show_iterations = []
-
-        def intercept(it, _):
-            assert it not in self.__processed_its, f'duplicate iteration {it}'
-            self.__processed_its.append(it)
-            encodings = trainer.network.encoding_prediction(trainer.data)
-            knn = None
-            if knn_k is not None:
-                from .knn import knn_graph
-                knn = knn_graph(np.ascontiguousarray(encodings, dtype=np.float32), knn_k)
-            if dims is None:
-                doc = schema.encits_document(self.enc_run_id, it, encodings, self.barcodes, knn=knn)
-            else:
-                doc = schema.encits_from_wide(self.enc_run_id, it, encodings, self.barcodes, dims=dims, knn=knn)
-            doc['cids'] = self.cell_ids
-            self.__coll(ITERATIONS_COLLECTION).insert_one(doc)
-            show_iterations.append(it)
-            self.__coll(ENCODINGS_COLLECTION).update_one(
-                {'_id': self.enc_run_id},
-                {'$set': {'defit': it, 'showits': show_iterations}}
-            )
-
-        return intercept
+        _require(self.barcodes, 'Cannot store iterations without barcodes!')
+        return _IterationWriter(self, trainer, dims, knn_k)

@@ -19,4 +19,9 @@ for arch, g, e, n in [('cont', 30000, 64, 96), ('cont', 2000, 32, 512), ('cls', 
         enc.set_weights(ws)
         out = enc.predict(m)
         row[dt] = float(np.max(np.abs(out - truth) / np.abs(truth)))
+    for name, kw in (('f32_sparse', dict(sparse=True)), ('f32_low_latency', dict(low_latency=True))):
+        enc = cc.HipEncoder(e, g, arch, **kw)
+        enc.set_weights(ws)
+        out = enc.predict(m)                    # n <= 128 rows take the split-K form with low_latency
+        row[name] = float(np.max(np.abs(out - truth) / np.abs(truth)))
     print(arch, g, e, n, {k: f'{v:.2e}' for k, v in row.items()})
