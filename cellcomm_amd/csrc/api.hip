@@ -120,6 +120,8 @@ struct Encoder {
   PackedWeight L2a;                // cont: the hidden-activation rows of K2 (+ b2) for the dense MFMA part of layer 2
   float *h1_all = nullptr;
   int64_t h1_rows = 0;
+  DevBuf out_buf;                  // [n x E] results of a host-output call before they cross PCIe (kept across calls:
+                                   // two device allocations per call were ~20 % of a batch-32 call)
   int64_t fallback_passes = 0;
   int64_t w0 = 0, w1 = 0;  // hidden widths of the first two layers
   int64_t batch = 8192;
@@ -607,6 +609,7 @@ void cc_encoder_free(void *enc) {
   encoder_free_ws(e);
   for (auto &l : e->L) free_weight(&l);
   for (auto &l : e->L16) free_weight16(&l);
+  e->out_buf.release();
   free_weight(&e->L2a);
   free_spmm_weight(&e->S1);
   free_spmm_weight(&e->S2);
@@ -748,10 +751,9 @@ int cc_encode_dev(void *enc, void *csr, const int64_t *row_ids, int64_t row_star
 int cc_encode(void *enc, void *csr, const int64_t *row_ids, int64_t row_start, int64_t n, float *host_out) {
   Encoder *e = static_cast<Encoder *>(enc);
   if (n <= 0) return encode_csr_dev(e, static_cast<Csr *>(csr), row_ids, row_start, n, nullptr);
-  DevPtr out;
-  CC_HIP(out.alloc(sizeof(float) * (size_t)(n * e->E)));
-  if (int rc = encode_csr_dev(e, static_cast<Csr *>(csr), row_ids, row_start, n, out.as<float>())) return rc;
-  CC_HIP(hipMemcpy(host_out, out.p, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost));
+  if (int rc = e->out_buf.alloc(sizeof(float) * (size_t)(n * e->E))) return rc;
+  if (int rc = encode_csr_dev(e, static_cast<Csr *>(csr), row_ids, row_start, n, e->out_buf.as<float>())) return rc;
+  CC_HIP(hipMemcpy(host_out, e->out_buf.p, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost));
   return CC_OK;
 }
 
@@ -769,9 +771,10 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
   if (e->dirty && (rc = encoder_pack(e))) return rc;
   e->fallback_passes = 0;
   if (n == 0) return CC_OK;
-  // passes of at most 2048 rows (or the encoder's own pass size when that is smaller) keep the first,
-  // un-overlapped copy short
-  const int64_t cap = e->batch < 2048 ? e->batch : 2048;
+  // passes of at most 4096 rows (or the encoder's own pass size when that is smaller): 4096 x 24 tiles are one whole
+  // round of the fp32 layer-1 kernel (768 resident tiles), shorter passes leave it half empty; the first copy
+  // (10 ms at G = 30000) is the only one not hidden
+  const int64_t cap = e->batch < 4096 ? e->batch : 4096;
   const int64_t B = n < cap ? n : cap;
   const int64_t npass = ceil_div(n, B);
   const int slots = npass > 1 ? 2 : 1;
@@ -780,8 +783,8 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
     if (!g_slot_free[sl]) CC_HIP(hipEventCreateWithFlags(&g_slot_free[sl], hipEventDisableTiming));
     if (!g_slot_full[sl]) CC_HIP(hipEventCreateWithFlags(&g_slot_full[sl], hipEventDisableTiming));
   }
-  DevPtr out;
-  CC_HIP(out.alloc(sizeof(float) * (size_t)(n * e->E)));
+  if ((rc = e->out_buf.alloc(sizeof(float) * (size_t)(n * e->E)))) return rc;
+  float *const d_out = e->out_buf.as<float>();
   CC_HIP(hipStreamSynchronize(g_stream));   // workspace memsets
   struct Drain {   // an early return must not leave copies or kernels running on buffers about to be freed
     ~Drain() { (void)hipStreamSynchronize(g_stream); (void)hipStreamSynchronize(g_stream2); g_cur = nullptr; }
@@ -809,14 +812,14 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
       CC_HIP(hipMemcpyAsync(&flag, e->d_flag[sl], sizeof(int), hipMemcpyDeviceToHost, g_stream));
       CC_HIP(hipStreamSynchronize(g_stream));
       if (fp16_pass_needs_fp32(e->dtype, flag)) { fp32_pass = true; e->fallback_passes += 1; }
-      else if ((rc = encoder_forward16(e, sl, m, out.as<float>() + off * e->E))) return rc;
+      else if ((rc = encoder_forward16(e, sl, m, d_out + off * e->E))) return rc;
     }
-    if (fp32_pass && (rc = encoder_forward(e, sl, m, out.as<float>() + off * e->E))) return rc;
+    if (fp32_pass && (rc = encoder_forward(e, sl, m, d_out + off * e->E))) return rc;
     CC_HIP(hipEventRecord(g_slot_free[sl], g_stream));
     if (pass + 1 < npass && (rc = copy_in(pass + 1))) return rc;   // crosses PCIe underneath the kernels just enqueued
   }
   CC_HIP(hipStreamSynchronize(g_stream));
-  CC_HIP(hipMemcpy(host_out, out.p, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost));
+  CC_HIP(hipMemcpy(host_out, d_out, sizeof(float) * (size_t)(n * e->E), hipMemcpyDeviceToHost));
   return CC_OK;
 }
 

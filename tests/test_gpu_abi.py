@@ -45,9 +45,9 @@ def test_two_encoders_of_different_width_interleaved(hip):
 
 
 def test_dense_host_pipeline_equals_csr_path(hip):
-    """cc_encode_dense runs passes of <= 2048 rows through two slots on two streams (copy of pass i+1 under the
+    """cc_encode_dense runs passes of <= 4096 rows through two slots on two streams (copy of pass i+1 under the
     kernels of pass i): 5 passes incl. a ragged last one, all three dtypes."""
-    g, e, n = 1024, 16, 2048 * 4 + 777
+    g, e, n = 1024, 16, 4096 * 4 + 777
     m = synth.synth_csr(n, g, seed=3)
     dense = m.to_dense()
     for dtype in ('f32', 'f16x2', 'f16'):
