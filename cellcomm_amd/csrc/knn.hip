@@ -924,6 +924,205 @@ __global__ __launch_bounds__(256, CC_KNN_C16_MINW) void knn_collect16_kernel(
   wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
 }
 
+// ---- stage 1b, coarse form of the collect (default) ------------------------------------------------------------
+// The 3-product tile above evaluates every (query, candidate) pair to ~2^-22, but only ~1.3 of a tile's 1024 pairs
+// pass the threshold.  Here the tile is the hi·hi product alone (ND + 1 MFMAs instead of 3·ND + 1: 5 instead of 13
+// at d = 64), accurate to 2^-10 of (‖q−μ‖² + ‖c−μ‖²); pairs at or below T + that bound are parked, and when a wave's
+// parking buffer is flushed each lane re-evaluates ONE parked pair directly, Σ (q_j − c_j)² in fp32 from the
+// original coordinates (error ~d·2^-24 of the distance itself), and only pairs with that distance <= T are appended.
+// What stage 2 needs holds a fortiori: an unlisted candidate either failed the coarse test (true distance > T) or the
+// fine one (true distance > T − ε_fine, ε_fine far below the ε of the certificate).
+//
+// Bound of the coarse tile (scaled by s²):  |acc − s²·dist| <= 2·Σ|qh·ch − s²·q·c| + fp32 accumulation.  Each operand
+// is y·s rounded to fp16: relative 2^-11 above the subnormal range (|y·s| >= 2^-14), absolute 2^-25 below it, so
+// |qh_i·ch_i − s²q_i c_i| <= (2^-10 + 2^-22) s²|q_i c_i| + 2^-25·2^7·2 ; summed (Cauchy-Schwarz, 2|q||c| <= |q|²+|c|²)
+// and doubled for the −2q·c factor: <= 2^-10·1.001·s²(‖q‖² + ‖c‖²) + d·2^-16, plus 16(ND+1) fp32 roundings on terms that
+// sum to <= 3 s²(‖q‖² + ‖c‖²) (2^-18 relative).  Used: 2^-9 · s²(‖q−μ‖² + max‖c−μ‖²) + d·2^-15  (>= 1.9x the bound).
+constexpr int C16C_CB = 4;   // candidate blocks per LDS stage (a block's hi + norm units: (ND + 1) KiB)
+
+struct WaveBufC {
+  unsigned *cand;   // [COL_WB] candidate index
+  int *qr;          // [COL_WB] query column 0..31
+  int n;
+};
+
+__device__ __forceinline__ float fine_dist(const float *__restrict__ xq, const float *__restrict__ xc, int d, int vec) {
+  float sum = 0.f;
+  if (vec) {
+    for (int t = 0; t < d; t += 4) {
+      const float4 a = *reinterpret_cast<const float4 *>(xq + t), b = *reinterpret_cast<const float4 *>(xc + t);
+      float df = a.x - b.x; sum = fmaf(df, df, sum);
+      df = a.y - b.y; sum = fmaf(df, df, sum);
+      df = a.z - b.z; sum = fmaf(df, df, sum);
+      df = a.w - b.w; sum = fmaf(df, df, sum);
+    }
+  } else {
+    for (int t = 0; t < d; ++t) {
+      const float df = xq[t] - xc[t];
+      sum = fmaf(df, df, sum);
+    }
+  }
+  return sum;
+}
+
+__device__ __forceinline__ void wavebufc_flush(WaveBufC &wb, const float *__restrict__ x, int d, int vec, int64_t q_begin,
+                                               const float *__restrict__ T, u64 *__restrict__ buf,
+                                               int *__restrict__ cursor, int64_t q0, int64_t n_q, int cap, int lane) {
+  for (int i = lane; i < wb.n; i += 64) {
+    const int64_t ql = q0 + wb.qr[i];
+    if (ql < n_q) {
+      const unsigned cand = wb.cand[i];
+      const float fine = fine_dist(x + (q_begin + ql) * d, x + (int64_t)cand * d, d, vec);
+      if (fine <= T[ql]) {
+        const int pos = atomicAdd(cursor + ql, 1);
+        if (pos < cap) buf[ql * cap + pos] = ((u64)f32_to_ordered(fine) << 32) | (u64)cand;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  wb.n = 0;
+}
+
+template <int ND>
+__global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
+    const h8 *__restrict__ P16, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
+    const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin,
+    int64_t n_q, int include_self, const float *__restrict__ T, float s, int S, int64_t NBs, int cap,
+    u64 *__restrict__ buf, int *__restrict__ cursor) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NT = 2 * ND + 1;             // units per candidate block in the panel
+  constexpr int HU = (ND + 1) * 64;          // hi + norm units of a block: what this kernel stages
+  constexpr int STAGE_U = C16C_CB * HU;
+  h8 *stage = reinterpret_cast<h8 *>(smem);  // [2][STAGE_U], then the 4 parking buffers
+
+  const int64_t tile = blockIdx.x / S;
+  const int split = blockIdx.x % S;
+  const int64_t b_lo = split * NBs;
+  const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int64_t ql = tile * 128 + wave * 32 + r;
+  const bool qvalid = ql < n_q;
+  const int64_t q = q_begin + ql;
+  const float s2 = s * s;
+  const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
+
+  h8 bqh[ND + 1];
+#pragma unroll
+  for (int t = 0; t <= ND; ++t) bqh[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
+  // coarse threshold in the tile's scaled units (see the bound above)
+  float Ts = -INFINITY;
+  if (qvalid) {
+    const float nsum = norms[q] + __uint_as_float(maxnorm_bits[0]);
+    Ts = (T[ql] + 1.953125e-3f * nsum) * s2 + (float)d * 3.0517578125e-5f;
+  }
+  const int64_t q0 = tile * 128 + wave * 32;
+  WaveBufC wb;
+  wb.cand = reinterpret_cast<unsigned *>(smem + sizeof(h8) * 2 * STAGE_U) + wave * COL_WB;
+  wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * 2 * STAGE_U + sizeof(unsigned) * 4 * COL_WB) + wave * COL_WB;
+  wb.n = 0;
+
+  int64_t self_blk = -1;
+  int self_e = -1;
+  if (qvalid && !include_self) {
+    const int row = (int)(q & 31);
+    if (((row >> 2) & 1) == h) {
+      self_blk = q >> 5;
+      self_e = (row & 3) | ((row >> 3) << 2);
+    }
+  }
+  unsigned tail_vm = 0xffffu;
+#pragma unroll
+  for (int e = 0; e < 16; ++e)
+    if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
+
+  const int64_t nstages = (b_hi - b_lo + C16C_CB - 1) / C16C_CB;
+  const f32x4 *Pv = reinterpret_cast<const f32x4 *>(P16);
+  f32x4 *stage_v = reinterpret_cast<f32x4 *>(smem);
+  constexpr int NS = (STAGE_U + 255) / 256;
+  int s_cb[NS], s_off[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    int f = i * 256 + tid;
+    f = f < STAGE_U ? f : STAGE_U - 1;
+    s_cb[i] = f / HU;
+    s_off[i] = f - s_cb[i] * HU;
+  }
+  f32x4 rs[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    int64_t b = b_lo + s_cb[i];
+    b = b < b_hi ? b : b_hi - 1;
+    rs[i] = Pv[b * (NT * 64) + s_off[i]];
+  }
+#pragma unroll
+  for (int i = 0; i < NS; ++i) stage_v[s_cb[i] * HU + s_off[i]] = rs[i];
+  __syncthreads();
+
+  int cur = 0;
+  for (int64_t st = 0; st < nstages; ++st) {
+    const bool more = st + 1 < nstages;
+    if (more) {
+#pragma unroll
+      for (int i = 0; i < NS; ++i) {
+        int64_t b = b_lo + (st + 1) * C16C_CB + s_cb[i];
+        b = b < b_hi ? b : b_hi - 1;
+        rs[i] = Pv[b * (NT * 64) + s_off[i]];
+      }
+    }
+    const h8 *sbuf = stage + cur * STAGE_U;
+#pragma unroll
+    for (int cb = 0; cb < C16C_CB; ++cb) {
+      const int64_t b = b_lo + st * C16C_CB + cb;
+      if (b < b_hi) {
+        const h8 *sb = sbuf + cb * HU;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        h8 ah[ND + 1];
+#pragma unroll
+        for (int t = 0; t <= ND; ++t) ah[t] = sb[t * 64 + lane];
+#pragma unroll
+        for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bqh[t], acc, 0, 0, 0);
+        if (__any(b == self_blk) || b == NB - 1) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const bool kill = (b == self_blk && e == self_e) || (b == NB - 1 && !((tail_vm >> e) & 1u));
+            acc[e] = kill ? __builtin_nanf("") : acc[e];
+          }
+        }
+        const unsigned cbase = (unsigned)(b * 32) + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool pass = acc[e] <= Ts;
+          const unsigned long long mask = __ballot(pass);
+          if (mask) {   // wave-uniform
+            const int cnt = __builtin_popcountll(mask);
+            if (wb.n + cnt > COL_WB) wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
+            if (pass) {
+              const int pos = wb.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+              wb.cand[pos] = cbase + (e & 3) + 8 * (e >> 2);
+              wb.qr[pos] = r;
+            }
+            wb.n += cnt;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (more) {
+      f32x4 *dbuf = stage_v + (cur ^ 1) * STAGE_U;
+#pragma unroll
+      for (int i = 0; i < NS; ++i) dbuf[s_cb[i] * HU + s_off[i]] = rs[i];
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
+}
+
 __global__ void knn_fill_kernel(float *__restrict__ p, int64_t n, float v) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -1341,6 +1540,7 @@ struct KnnWorkspace {
   bool use_fp16_select = CC_KNN_SELECT16 != 0;   // sample pass of stage 1b on the fp16 matrix cores too
   bool use_fp16_collect = true;            // stage 1b collect on the fp16 matrix cores when the data's scale allows
   bool use_fp64_prefilter = true;          // stage 3: float64 matrix-core prefilter in front of the exact scan
+  bool use_coarse_collect = true;          // stage 1b collect as hi·hi tile + direct fp32 re-evaluation of the parked pairs
   int collect_splits = 0;                  // 0 = chosen per call; > 0 = forced (tools/knn_split_sweep.sh)
   int64_t last_fallback = 0;
   int64_t last_full_scan = 0;              // fallback queries that had to scan every candidate in float64 VALU
@@ -1454,6 +1654,26 @@ static int run_collect16(int ND, const h8 *P16, const SelectArgs &a, const float
 }
 
 // split the NB candidate blocks into S contiguous ranges of NBs blocks (last may be short)
+static int run_collect16c(int ND, const h8 *P16, const SelectArgs &a, const unsigned *maxnorm_bits, const float *T, float s,
+                          int S, int64_t NBs, int cap, u64 *buf, int *cursor) {
+  const int64_t nwg = ceil_div(a.n_q, 128) * S;
+#define CC_COL16C(NDV)                                                                                            \
+  case NDV: {                                                                                                     \
+    const size_t lds = sizeof(h8) * 2 * C16C_CB * (NDV + 1) * 64 + (sizeof(unsigned) + sizeof(int)) * 4 * COL_WB; \
+    hipLaunchKernelGGL(knn_collect16c_kernel<NDV>, dim3((unsigned)nwg), dim3(256), lds, stream(), P16, a.norms,   \
+                       maxnorm_bits, a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, NBs,   \
+                       cap, buf, cursor);                                                                         \
+    break;                                                                                                        \
+  }
+  switch (ND) {
+    CC_COL16C(1) CC_COL16C(2) CC_COL16C(4) CC_COL16C(8)
+    default: CC_REQUIRE(false, "knn: no coarse fp16 collect kernel for ND=%d", ND);
+  }
+#undef CC_COL16C
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
 static void make_splits(int64_t NB, int want, int *S, int64_t *NBs) {
   int s = want < 1 ? 1 : want;
   while (s > 1 && NB / s < 16) --s;
@@ -1661,8 +1881,12 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
       if ((rc = ccur.alloc(sizeof(int) * (size_t)n_q))) return rc;
       CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
       if (scale16 > 0.f) {
-        if ((rc = run_collect16(ND16, P16.as<h8>(), sa, Tq.as<float>(), scale16, S, NBs, col_cap, cbuf.as<u64>(),
-                                ccur.as<int>())))
+        if (ws.use_coarse_collect && !collect_all) {
+          if ((rc = run_collect16c(ND16, P16.as<h8>(), sa, maxn.as<unsigned>(), Tq.as<float>(), scale16, S, NBs, col_cap,
+                                   cbuf.as<u64>(), ccur.as<int>())))
+            return rc;
+        } else if ((rc = run_collect16(ND16, P16.as<h8>(), sa, Tq.as<float>(), scale16, S, NBs, col_cap, cbuf.as<u64>(),
+                                       ccur.as<int>())))
           return rc;
         // error bound of the fp16-split tile, relative to (‖q−μ‖² + ‖c−μ‖²), u = 2^-24:
         //   16(3·ND+1) product terms accumulated in fp32 on |terms| summing to <= 3(‖q‖²+‖c‖²)
@@ -1829,6 +2053,7 @@ int cc_knn_set_option(void *knn, int option, int value) {
     case CC_KNN_OPT_FP16_COLLECT: ws->use_fp16_collect = value != 0; break;
     case CC_KNN_OPT_FP16_SELECT: ws->use_fp16_select = value != 0; break;
     case CC_KNN_OPT_FP64_PREFILTER: ws->use_fp64_prefilter = value != 0; break;
+    case CC_KNN_OPT_COARSE_COLLECT: ws->use_coarse_collect = value != 0; break;
     case CC_KNN_OPT_COLLECT_SPLITS:
       CC_REQUIRE(value >= 0 && value <= 64, "collect splits %d outside [0, 64]", value);
       ws->collect_splits = value;

@@ -63,6 +63,12 @@ def use_fp16_collect(on):
     _lib.check(_lib.lib().cc_knn_use_fp16_collect(1 if on else 0))
 
 
+def use_coarse_collect(on):
+    """Stage 1b collect as ONE fp16 product per pair + direct fp32 re-evaluation of the parked pairs (default), or
+    the three-product tile for every pair; same results, different speed (CC_KNN_OPT_COARSE_COLLECT)."""
+    _lib.check(_lib.lib().cc_knn_set_option(None, 6, 1 if on else 0))
+
+
 def use_fp64_prefilter(on):
     """Stage 3: narrow each uncertified query's candidates with a float64 matrix-core pass (default) before
     the exact evaluation, or scan all candidates; same results, different speed."""

@@ -137,6 +137,40 @@ def test_few_uncertified_queries_scan_in_parallel(hip, oracle_built, n_q, k):
     assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d)
 
 
+@pytest.mark.parametrize('kind', ['uniform', 'far_from_origin', 'tight_clusters', 'dup_heavy', 'tiny_scale', 'mixed_scale'])
+def test_coarse_and_three_product_collect_agree(hip, oracle_built, kind):
+    """The collect pass keeps a pair when ONE fp16 product puts it within T + its error bound and the direct fp32
+    re-evaluation confirms it (default), or evaluates every pair with three products (option off): the neighbour
+    lists must be the oracle's either way, on data that stresses the coarse bound (large norms against small
+    distances, denormal-range coordinates, exact duplicates)."""
+    rng = np.random.default_rng(len(kind))
+    n, d, k = 9000, 64, 15
+    if kind == 'uniform':
+        x = rng.random((n, d), dtype=np.float32)
+    elif kind == 'far_from_origin':
+        x = (rng.random((n, d)) * 1e-2 + 50.0).astype(np.float32)
+        x[:4500, :8] += 30.0                                  # two far-apart groups: large centred norms, small distances
+    elif kind == 'tight_clusters':
+        c = rng.random((30, d), dtype=np.float32) * 10
+        x = (c[np.sort(rng.integers(0, 30, n))] + rng.standard_normal((n, d)).astype(np.float32) * 0.01).astype(np.float32)
+    elif kind == 'dup_heavy':
+        sites = rng.random((200, d), dtype=np.float32)
+        x = sites[rng.integers(0, 200, n)]
+    elif kind == 'tiny_scale':
+        x = (rng.random((n, d)) * 1e-20).astype(np.float32)
+    else:
+        x = rng.random((n, d), dtype=np.float32)
+        x[:, ::2] *= 1e-6                                     # half the coordinates fall into the fp16 subnormal range
+    want_i, want_d = ko.knn(x, k)
+    for coarse in (True, False):
+        hipknn.use_coarse_collect(coarse)
+        try:
+            idx, dist = cc.knn_graph(x, k)
+        finally:
+            hipknn.use_coarse_collect(True)
+        assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (kind, coarse)
+
+
 def test_near_ties_below_fp32_resolution(hip, oracle_built):
     # neighbours whose distances differ by far less than the fp32 error of stage 1
     rng = np.random.default_rng(6)
