@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
     const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin,
     int64_t n_q, int include_self, const float *__restrict__ T, float s, int S, int64_t NBs, int cap,
-    u64 *__restrict__ buf, int *__restrict__ cursor) {
+    u64 *__restrict__ buf, int *__restrict__ cursor, int min_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NT = 2 * ND + 1;             // units per candidate block in the panel
   constexpr int HU = (ND + 1) * 64;          // hi + norm units of a block: what this kernel stages
@@ -1093,6 +1093,20 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
           }
         }
         const unsigned cbase = (unsigned)(b * 32) + 4 * h;
+        if (min_first) {
+          // few pairs pass per tile when the candidate set is large (1024 * 8m / N expected: 0.13 at N = 1M): one
+          // min3 tree + one ballot rejects the whole tile instead of 16 compare + branch pairs (NaN = killed entries
+          // drop out of fminf)
+          float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
+          mn = fminf(fminf(mn, acc[3]), acc[4]);
+          mn = fminf(fminf(mn, acc[5]), acc[6]);
+          mn = fminf(fminf(mn, acc[7]), acc[8]);
+          mn = fminf(fminf(mn, acc[9]), acc[10]);
+          mn = fminf(fminf(mn, acc[11]), acc[12]);
+          mn = fminf(fminf(mn, acc[13]), acc[14]);
+          mn = fminf(mn, acc[15]);
+          if (!__any(mn <= Ts)) continue;
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const bool pass = acc[e] <= Ts;
@@ -1657,12 +1671,14 @@ static int run_collect16(int ND, const h8 *P16, const SelectArgs &a, const float
 static int run_collect16c(int ND, const h8 *P16, const SelectArgs &a, const unsigned *maxnorm_bits, const float *T, float s,
                           int S, int64_t NBs, int cap, u64 *buf, int *cursor) {
   const int64_t nwg = ceil_div(a.n_q, 128) * S;
+  // expected pairs of a 32 x 32 tile under the threshold: ~cap / 4 collected per query out of N candidates
+  const int min_first = (1024.0 * (double)(cap / 4) / (double)a.N) < 0.5 ? 1 : 0;
 #define CC_COL16C(NDV)                                                                                            \
   case NDV: {                                                                                                     \
     const size_t lds = sizeof(h8) * 2 * C16C_CB * (NDV + 1) * 64 + (sizeof(unsigned) + sizeof(int)) * 4 * COL_WB; \
     hipLaunchKernelGGL(knn_collect16c_kernel<NDV>, dim3((unsigned)nwg), dim3(256), lds, stream(), P16, a.norms,   \
                        maxnorm_bits, a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, NBs,   \
-                       cap, buf, cursor);                                                                         \
+                       cap, buf, cursor, min_first);                                                              \
     break;                                                                                                        \
   }
   switch (ND) {
