@@ -983,7 +983,11 @@ __device__ __forceinline__ void wavebufc_flush(WaveBufC &wb, const float *__rest
   wb.n = 0;
 }
 
-template <int ND>
+// QW = 32-query groups per wave: 2 makes a workgroup own 256 queries, so a candidate panel crosses the fabric and LDS
+// once per 256 queries instead of 128 (at N = 1M the panels no longer fit the L2s: 152 GB of panel reads for one
+// rank's search with QW = 1) and every fragment read feeds two MFMA chains; 1 keeps more workgroups for short query
+// ranges.
+template <int ND, int QW>
 __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
     const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin,
@@ -993,6 +997,7 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
   constexpr int NT = 2 * ND + 1;             // units per candidate block in the panel
   constexpr int HU = (ND + 1) * 64;          // hi + norm units of a block: what this kernel stages
   constexpr int STAGE_U = C16C_CB * HU;
+  constexpr int QPW = 32 * QW;               // queries per wave
   h8 *stage = reinterpret_cast<h8 *>(smem);  // [2][STAGE_U], then the 4 parking buffers
 
   const int64_t tile = blockIdx.x / S;
@@ -1002,36 +1007,43 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t ql = tile * 128 + wave * 32 + r;
-  const bool qvalid = ql < n_q;
-  const int64_t q = q_begin + ql;
   const float s2 = s * s;
   const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
+  const int64_t q0 = tile * (4 * QPW) + wave * QPW;
 
-  h8 bqh[ND + 1];
+  h8 bqh[QW][ND + 1];
+  float Ts[QW];
+  int64_t self_blk[QW];
+  int self_e[QW];
 #pragma unroll
-  for (int t = 0; t <= ND; ++t) bqh[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
-  // coarse threshold in the tile's scaled units (see the bound above)
-  float Ts = -INFINITY;
-  if (qvalid) {
-    const float nsum = norms[q] + __uint_as_float(maxnorm_bits[0]);
-    Ts = (T[ql] + 1.953125e-3f * nsum) * s2 + (float)d * 3.0517578125e-5f;
+  for (int g = 0; g < QW; ++g) {
+    const int64_t ql = q0 + g * 32 + r;
+    const bool qvalid = ql < n_q;
+    const int64_t q = q_begin + ql;
+#pragma unroll
+    for (int t = 0; t <= ND; ++t)
+      bqh[g][t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
+    // coarse threshold in the tile's scaled units (see the bound above)
+    Ts[g] = -INFINITY;
+    if (qvalid) {
+      const float nsum = norms[q] + __uint_as_float(maxnorm_bits[0]);
+      Ts[g] = (T[ql] + 1.953125e-3f * nsum) * s2 + (float)d * 3.0517578125e-5f;
+    }
+    self_blk[g] = -1;
+    self_e[g] = -1;
+    if (qvalid && !include_self) {
+      const int row = (int)(q & 31);
+      if (((row >> 2) & 1) == h) {
+        self_blk[g] = q >> 5;
+        self_e[g] = (row & 3) | ((row >> 3) << 2);
+      }
+    }
   }
-  const int64_t q0 = tile * 128 + wave * 32;
   WaveBufC wb;
   wb.cand = reinterpret_cast<unsigned *>(smem + sizeof(h8) * 2 * STAGE_U) + wave * COL_WB;
   wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * 2 * STAGE_U + sizeof(unsigned) * 4 * COL_WB) + wave * COL_WB;
   wb.n = 0;
 
-  int64_t self_blk = -1;
-  int self_e = -1;
-  if (qvalid && !include_self) {
-    const int row = (int)(q & 31);
-    if (((row >> 2) & 1) == h) {
-      self_blk = q >> 5;
-      self_e = (row & 3) | ((row >> 3) << 2);
-    }
-  }
   unsigned tail_vm = 0xffffu;
 #pragma unroll
   for (int e = 0; e < 16; ++e)
@@ -1077,53 +1089,56 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
       const int64_t b = b_lo + st * C16C_CB + cb;
       if (b < b_hi) {
         const h8 *sb = sbuf + cb * HU;
-        f32x16 acc;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
         h8 ah[ND + 1];
 #pragma unroll
         for (int t = 0; t <= ND; ++t) ah[t] = sb[t * 64 + lane];
+        const unsigned cbase = (unsigned)(b * 32) + 4 * h;
 #pragma unroll
-        for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bqh[t], acc, 0, 0, 0);
-        if (__any(b == self_blk) || b == NB - 1) {
+        for (int g = 0; g < QW; ++g) {
+          f32x16 acc;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+          for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bqh[g][t], acc, 0, 0, 0);
+          if (__any(b == self_blk[g]) || b == NB - 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const bool kill = (b == self_blk[g] && e == self_e[g]) || (b == NB - 1 && !((tail_vm >> e) & 1u));
+              acc[e] = kill ? __builtin_nanf("") : acc[e];
+            }
+          }
+          if (min_first) {
+            // few pairs pass per tile when the candidate set is large (1024 * 8m / N expected: 0.13 at N = 1M): one
+            // min3 tree + one ballot rejects the whole tile instead of 16 compare + branch pairs (NaN = killed
+            // entries drop out of fminf)
+            float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
+            mn = fminf(fminf(mn, acc[3]), acc[4]);
+            mn = fminf(fminf(mn, acc[5]), acc[6]);
+            mn = fminf(fminf(mn, acc[7]), acc[8]);
+            mn = fminf(fminf(mn, acc[9]), acc[10]);
+            mn = fminf(fminf(mn, acc[11]), acc[12]);
+            mn = fminf(fminf(mn, acc[13]), acc[14]);
+            mn = fminf(mn, acc[15]);
+            if (!__any(mn <= Ts[g])) continue;
+          }
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const bool kill = (b == self_blk && e == self_e) || (b == NB - 1 && !((tail_vm >> e) & 1u));
-            acc[e] = kill ? __builtin_nanf("") : acc[e];
-          }
-        }
-        const unsigned cbase = (unsigned)(b * 32) + 4 * h;
-        if (min_first) {
-          // few pairs pass per tile when the candidate set is large (1024 * 8m / N expected: 0.13 at N = 1M): one
-          // min3 tree + one ballot rejects the whole tile instead of 16 compare + branch pairs (NaN = killed entries
-          // drop out of fminf)
-          float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
-          mn = fminf(fminf(mn, acc[3]), acc[4]);
-          mn = fminf(fminf(mn, acc[5]), acc[6]);
-          mn = fminf(fminf(mn, acc[7]), acc[8]);
-          mn = fminf(fminf(mn, acc[9]), acc[10]);
-          mn = fminf(fminf(mn, acc[11]), acc[12]);
-          mn = fminf(fminf(mn, acc[13]), acc[14]);
-          mn = fminf(mn, acc[15]);
-          if (!__any(mn <= Ts)) continue;
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const bool pass = acc[e] <= Ts;
-          const unsigned long long mask = __ballot(pass);
-          if (mask) {   // wave-uniform
-            const int cnt = __builtin_popcountll(mask);
-            if (wb.n + cnt > COL_WB) wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
-            if (pass) {
-              const int pos = wb.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                    __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-              wb.cand[pos] = cbase + (e & 3) + 8 * (e >> 2);
-              wb.qr[pos] = r;
+            const bool pass = acc[e] <= Ts[g];
+            const unsigned long long mask = __ballot(pass);
+            if (mask) {   // wave-uniform
+              const int cnt = __builtin_popcountll(mask);
+              if (wb.n + cnt > COL_WB) wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
+              if (pass) {
+                const int pos = wb.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+                wb.cand[pos] = cbase + (e & 3) + 8 * (e >> 2);
+                wb.qr[pos] = g * 32 + r;
+              }
+              wb.n += cnt;
             }
-            wb.n += cnt;
           }
+          __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_wave_barrier();
       }
     }
     if (more) {
@@ -1668,22 +1683,31 @@ static int run_collect16(int ND, const h8 *P16, const SelectArgs &a, const float
 }
 
 // split the NB candidate blocks into S contiguous ranges of NBs blocks (last may be short)
-static int run_collect16c(int ND, const h8 *P16, const SelectArgs &a, const unsigned *maxnorm_bits, const float *T, float s,
-                          int S, int64_t NBs, int cap, u64 *buf, int *cursor) {
-  const int64_t nwg = ceil_div(a.n_q, 128) * S;
+static int run_collect16c(int ND, int QW, const h8 *P16, const SelectArgs &a, const unsigned *maxnorm_bits, const float *T,
+                          float s, int S, int64_t NBs, int cap, u64 *buf, int *cursor) {
+  const int64_t nwg = ceil_div(a.n_q, 128 * QW) * S;
   // expected pairs of a 32 x 32 tile under the threshold: ~cap / 4 collected per query out of N candidates
   const int min_first = (1024.0 * (double)(cap / 4) / (double)a.N) < 0.5 ? 1 : 0;
-#define CC_COL16C(NDV)                                                                                            \
-  case NDV: {                                                                                                     \
-    const size_t lds = sizeof(h8) * 2 * C16C_CB * (NDV + 1) * 64 + (sizeof(unsigned) + sizeof(int)) * 4 * COL_WB; \
-    hipLaunchKernelGGL(knn_collect16c_kernel<NDV>, dim3((unsigned)nwg), dim3(256), lds, stream(), P16, a.norms,   \
-                       maxnorm_bits, a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, NBs,   \
-                       cap, buf, cursor, min_first);                                                              \
-    break;                                                                                                        \
-  }
-  switch (ND) {
-    CC_COL16C(1) CC_COL16C(2) CC_COL16C(4) CC_COL16C(8)
-    default: CC_REQUIRE(false, "knn: no coarse fp16 collect kernel for ND=%d", ND);
+#define CC_COL16C(NDV, QWV)                                                                                          \
+  hipLaunchKernelGGL((knn_collect16c_kernel<NDV, QWV>), dim3((unsigned)nwg), dim3(256),                              \
+                     sizeof(h8) * 2 * C16C_CB * (NDV + 1) * 64 + (sizeof(unsigned) + sizeof(int)) * 4 * COL_WB, stream(), \
+                     P16, a.norms, maxnorm_bits, a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, \
+                     NBs, cap, buf, cursor, min_first)
+  if (QW == 2) {
+    switch (ND) {
+      case 1: CC_COL16C(1, 2); break;
+      case 2: CC_COL16C(2, 2); break;
+      case 4: CC_COL16C(4, 2); break;
+      default: CC_REQUIRE(false, "knn: no two-group coarse collect kernel for ND=%d", ND);
+    }
+  } else {
+    switch (ND) {
+      case 1: CC_COL16C(1, 1); break;
+      case 2: CC_COL16C(2, 1); break;
+      case 4: CC_COL16C(4, 1); break;
+      case 8: CC_COL16C(8, 1); break;
+      default: CC_REQUIRE(false, "knn: no coarse fp16 collect kernel for ND=%d", ND);
+    }
   }
 #undef CC_COL16C
   CC_HIP(hipGetLastError());
@@ -1898,7 +1922,9 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
       CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
       if (scale16 > 0.f) {
         if (ws.use_coarse_collect && !collect_all) {
-          if ((rc = run_collect16c(ND16, P16.as<h8>(), sa, maxn.as<unsigned>(), Tq.as<float>(), scale16, S, NBs, col_cap,
+          // 256 queries per workgroup once that still leaves a full round of workgroups over the chip's 768 slots
+          const int QW = (ND16 <= 4 && ceil_div(n_q, 256) * S >= 768) ? 2 : 1;
+          if ((rc = run_collect16c(ND16, QW, P16.as<h8>(), sa, maxn.as<unsigned>(), Tq.as<float>(), scale16, S, NBs, col_cap,
                                    cbuf.as<u64>(), ccur.as<int>())))
             return rc;
         } else if ((rc = run_collect16(ND16, P16.as<h8>(), sa, Tq.as<float>(), scale16, S, NBs, col_cap, cbuf.as<u64>(),
