@@ -665,42 +665,23 @@ __global__ void knn_pack16_kernel(const float *__restrict__ x, const float *__re
   P16[f] = panel16_unit(x, mu, norms, cand, cand < N, d, ND, t, lane >> 5, s, s * s * (1.0f / 256.0f), false);
 }
 
-// ---- sample select on the fp16 matrix cores --------------------------------------------------
-// Same lists, same filter as knn_select_kernel; the 32 x 32 tile comes from the fp16-split panels
-// (3·ND + 1 MFMAs of 32 cycles instead of 4·NG of 64), in the arithmetic knn_collect16 filters with:
-// the threshold T then is a distance the collect pass reproduces bit for bit, so the m sampled points
-// that define it are always collected.  Distances live scaled by s² (a power of two) in the lists and
-// are unscaled, exactly, when the keys are written out.
-template <int ND>
-__device__ __forceinline__ void select16_step(const h8 (&ah)[ND + 1], const h8 (&al)[ND], const h8 (&bqh)[ND + 1],
-                                              const h8 (&bql)[ND], int64_t b, int64_t NB, int64_t self_blk, int self_e,
-                                              unsigned tail_vm, float &tau, u64 *list, float *tau_s, int *cnt, int LS,
-                                              int KP, int CAP, int lane) {
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-  for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bqh[t], acc, 0, 0, 0);
-#pragma unroll
-  for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bql[t], acc, 0, 0, 0);
-#pragma unroll
-  for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bqh[t], acc, 0, 0, 0);
-  select_filter(acc, b, NB, self_blk, self_e, tail_vm, tau, list, tau_s, cnt, LS, KP, CAP, lane);
-}
-
-template <int ND>
-__global__ __launch_bounds__(64, 3) void knn_select16_kernel(
+// ---- sample pass on the fp16 matrix cores: slot minima instead of lists -------------------------
+// The sample only has to produce a threshold T[q] under which at least m candidates lie.  A 32 x 32 tile leaves
+// each lane with 16 distances of ITS query to 16 candidates; the lane keeps the running minimum of every such
+// register slot over the sampled tiles, NSET interleaved sets of them (tile j feeds set j % NSET).  A query thus
+// ends with G = 32·NSET minima (x the candidate ranges the pass is split over), each the distance of a DIFFERENT
+// candidate, and T = the m-th smallest of them (knn_slot_threshold_kernel) has >= m candidates at or below it.
+// It is a little looser than the m-th best of the whole sample (two of the best m may share a slot: the expected
+// rank is G·ln(G/(G-m)), 18.4 instead of 16 at G = 64) but costs one v_min per distance instead of an LDS list
+// insertion, needs no LDS, and leaves the pass bound by its MFMAs and fragment loads.  Arithmetic: the 3·ND + 1
+// products of the fp16 split (hi·hi + hi·lo + lo·hi), scaled by s² (a power of two) and unscaled exactly on the
+// way out.
+template <int ND, int NSET>
+__global__ __launch_bounds__(64) void knn_sample16_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const float *__restrict__ x,
     const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
-    float s, int KP, int CAP, int S, int64_t NBs, int bstride, u64 *__restrict__ out_keys,
-    int *__restrict__ out_cnt) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+    float s, int S, int64_t NBs, int bstride, float *__restrict__ out_min) {
   constexpr int NT = 2 * ND + 1;
-  const int LS = CAP + 1;
-  u64 *list = reinterpret_cast<u64 *>(smem);
-  float *tau_s = reinterpret_cast<float *>(list + 32 * LS);
-  int *cnt = reinterpret_cast<int *>(tau_s + 32);
-
   const int64_t tile = blockIdx.x / S;
   const int split = blockIdx.x % S;
   const int64_t b_lo = split * NBs;
@@ -717,12 +698,6 @@ __global__ __launch_bounds__(64, 3) void knn_select16_kernel(
   for (int t = 0; t <= ND; ++t) bqh[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
 #pragma unroll
   for (int t = 0; t < ND; ++t) bql[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, ND + 1 + t, h, -2.0f * s, 0.f, true);
-  if (lane < 32) {
-    cnt[r] = 0;
-    tau_s[r] = qvalid ? INFINITY : -INFINITY;
-  }
-  __builtin_amdgcn_wave_barrier();
-  float tau = tau_s[r];
 
   int64_t self_blk = -1;
   int self_e = -1;
@@ -738,51 +713,95 @@ __global__ __launch_bounds__(64, 3) void knn_select16_kernel(
   for (int e = 0; e < 16; ++e)
     if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
 
-  // two register sets of candidate operands, ping-pong: block b+1 loads while b computes
-  h8 ah0[ND + 1], al0[ND], ah1[ND + 1], al1[ND];
+  f32x16 mn[NSET];
+#pragma unroll
+  for (int u = 0; u < NSET; ++u)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) mn[u][e] = INFINITY;
+
+  // two register sets of candidate operands, ping-pong: the next sampled block loads while this one computes
+  h8 ah[2][ND + 1], al[2][ND];
   {
     const h8 *pb = P16 + b_lo * (NT * 64) + lane;
 #pragma unroll
-    for (int t = 0; t <= ND; ++t) ah0[t] = pb[t * 64];
+    for (int t = 0; t <= ND; ++t) ah[0][t] = pb[t * 64];
 #pragma unroll
-    for (int t = 0; t < ND; ++t) al0[t] = pb[(ND + 1 + t) * 64];
+    for (int t = 0; t < ND; ++t) al[0][t] = pb[(ND + 1 + t) * 64];
   }
-  for (int64_t b = b_lo; b < b_hi; b += 2 * bstride) {
-    const int64_t b1 = b + bstride, b2 = b + 2 * bstride;
-    {
-      const h8 *pb = P16 + ((b1 < b_hi) ? b1 : b) * (NT * 64) + lane;
+  for (int64_t b0 = b_lo; b0 < b_hi; b0 += (int64_t)NSET * bstride) {
 #pragma unroll
-      for (int t = 0; t <= ND; ++t) ah1[t] = pb[t * 64];
+    for (int u = 0; u < NSET; ++u) {
+      const int64_t b = b0 + (int64_t)u * bstride;
+      if (b < b_hi) {   // wave-uniform
+        const int cur = u & 1, nxt = cur ^ 1;   // constants after unrolling
+        {
+          const int64_t bn = b + bstride;
+          const h8 *pb = P16 + ((bn < b_hi) ? bn : b) * (NT * 64) + lane;
 #pragma unroll
-      for (int t = 0; t < ND; ++t) al1[t] = pb[(ND + 1 + t) * 64];
-    }
-    select16_step<ND>(ah0, al0, bqh, bql, b, NB, self_blk, self_e, tail_vm, tau, list, tau_s, cnt, LS, KP, CAP, lane);
-    if (b1 < b_hi) {
-      {
-        const h8 *pb = P16 + ((b2 < b_hi) ? b2 : b1) * (NT * 64) + lane;
+          for (int t = 0; t <= ND; ++t) ah[nxt][t] = pb[t * 64];
 #pragma unroll
-        for (int t = 0; t <= ND; ++t) ah0[t] = pb[t * 64];
+          for (int t = 0; t < ND; ++t) al[nxt][t] = pb[(ND + 1 + t) * 64];
+        }
+        f32x16 acc;
 #pragma unroll
-        for (int t = 0; t < ND; ++t) al0[t] = pb[(ND + 1 + t) * 64];
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bqh[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bql[t], acc, 0, 0, 0);
+#pragma unroll
+        for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], bqh[t], acc, 0, 0, 0);
+        if (__any(b == self_blk) || b == NB - 1) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const bool kill = (b == self_blk && e == self_e) || (b == NB - 1 && !((tail_vm >> e) & 1u));
+            acc[e] = kill ? INFINITY : acc[e];
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) asm("v_min_f32 %0, %1, %2" : "=v"(mn[u][e]) : "v"(mn[u][e]), "v"(acc[e]));
       }
-      select16_step<ND>(ah1, al1, bqh, bql, b1, NB, self_blk, self_e, tail_vm, tau, list, tau_s, cnt, LS, KP, CAP, lane);
     }
   }
+  if (qvalid) {
+    // slot order inside a query's G values does not matter to the consumer
+    f32x4 *dst = reinterpret_cast<f32x4 *>(out_min + ((ql * S + split) * NSET * 32 + h * 16));
+#pragma unroll
+    for (int u = 0; u < NSET; ++u)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = mn[u][4 * j + i] * inv_s2;   // exact: s² is a power of two
+        dst[u * 8 + j] = v;
+      }
+  }
+}
 
-  for (int qi = 0; qi < 32; ++qi) {
-    compact_list(list + qi * LS, cnt + qi, tau_s + qi, KP, lane);
-    const int64_t qo = tile * 32 + qi;
-    if (qo < n_q) {
-      const int c = cnt[qi];
-      const int64_t slot = qo * S + split;
-      for (int i = lane; i < c; i += 64) {
-        const u64 e = list[qi * LS + i];
-        const float dist = ordered_to_f32((unsigned)(e >> 32)) * inv_s2;   // exact: s² is a power of two
-        out_keys[slot * KP + i] = ((u64)f32_to_ordered(dist) << 32) | (e & 0xffffffffull);
-      }
-      if (lane == 0) out_cnt[slot] = c;
-    }
+// T[q] = the m-th smallest of the query's n slot minima (n = 32·NSET·S, a multiple of 64; +inf when fewer than m
+// are finite).  One wave per query: bisection over the bits of the order-preserving integer image of the floats,
+// counting with ballots.
+__global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const float *__restrict__ smin, int64_t n_q, int n,
+                                                                 int m, float *__restrict__ T) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t ql = (int64_t)blockIdx.x * 4 + wave;
+  if (ql >= n_q) return;
+  constexpr int MAXR = 16;
+  unsigned key[MAXR];
+  const int nreg = n / 64;
+#pragma unroll
+  for (int j = 0; j < MAXR; ++j) key[j] = j < nreg ? f32_to_ordered(smin[ql * n + j * 64 + lane]) : 0xffffffffu;
+  unsigned prefix = 0;
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned trial = prefix | ((1u << bit) - 1u);
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < MAXR; ++j)
+      if (j < nreg) c += __builtin_popcountll(__ballot(key[j] <= trial));
+    if (c < m) prefix |= 1u << bit;
   }
+  const unsigned inf_key = f32_to_ordered(INFINITY);
+  if (lane == 0) T[ql] = prefix >= inf_key ? INFINITY : ordered_to_f32(prefix);
 }
 
 template <int ND>
@@ -1562,7 +1581,7 @@ __global__ __launch_bounds__(64) void knn_prefilter64_kernel(
 // the last call.  cc_knn_create / cc_knn_free own one; the convenience entry points (cc_knn_l2, cc_knn_l2_dev,
 // cc_knn_l2_sharded) use the library's default workspace, which cc_shutdown releases.
 struct KnnWorkspace {
-  DevBuf P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
+  DevBuf P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, smin, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
       bnd_d, bnd_i, partial, mu, norm64, max64, plist, pcnt, nfull, full_list, part_d, part_i;
   bool force_fallback = false;             // test hook: every query through the float64 stage
   bool force_route_a = false;              // test hook: always take the full-select route
@@ -1571,10 +1590,12 @@ struct KnnWorkspace {
   bool use_fp64_prefilter = true;          // stage 3: float64 matrix-core prefilter in front of the exact scan
   bool use_coarse_collect = true;          // stage 1b collect as hi·hi tile + direct fp32 re-evaluation of the parked pairs
   int collect_splits = 0;                  // 0 = chosen per call; > 0 = forced (tools/knn_split_sweep.sh)
+  int sample_splits = 0;                   // same for the candidate ranges of the fp16 sample pass
+  int sample_stride = 0;                   // 0 = CC_KNN_SAMPLE; > 0 = every n-th candidate block is sampled
   int64_t last_fallback = 0;
   int64_t last_full_scan = 0;              // fallback queries that had to scan every candidate in float64 VALU
   void release() {
-    DevBuf *all[] = {&P, &P16, &norms, &maxn, &keys, &cnts, &bound, &skeys, &scnts, &Tq, &cbuf, &ccur, &oidx, &odist,
+    DevBuf *all[] = {&P, &P16, &norms, &maxn, &keys, &cnts, &bound, &skeys, &scnts, &smin, &Tq, &cbuf, &ccur, &oidx, &odist,
                      &nflag, &flagged, &bnd_d, &bnd_i, &partial, &mu, &norm64, &max64, &plist, &pcnt, &nfull, &full_list, &part_d,
                      &part_i};
     for (DevBuf *b : all) b->release();
@@ -1617,21 +1638,28 @@ static int run_select(int NG, const SelectArgs &a, int KP, int CAP, int S, int64
   return CC_OK;
 }
 
-static int run_select16(int ND, const h8 *P16, const SelectArgs &a, float s, int KP, int CAP, int S, int64_t NBs,
-                        int bstride, u64 *keys, int *cnts) {
+static int run_sample16(int ND, int NSET, const h8 *P16, const SelectArgs &a, float s, int S, int64_t NBs, int bstride,
+                        float *out_min) {
   const int64_t nwaves = ceil_div(a.n_q, 32) * S;
-  const size_t lds = sizeof(u64) * 32 * (size_t)(CAP + 1) + 32 * 8;
-#define CC_SEL16(NDV)                                                                                          \
-  case NDV:                                                                                                    \
-    hipLaunchKernelGGL(knn_select16_kernel<NDV>, dim3((unsigned)nwaves), dim3(64), lds, stream(), P16, a.norms, \
-                       a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, s, KP, CAP, S, NBs, bstride, \
-                       keys, cnts);                                                                            \
-    break;
-  switch (ND) {
-    CC_SEL16(1) CC_SEL16(2) CC_SEL16(4) CC_SEL16(8)
-    default: CC_REQUIRE(false, "knn: no fp16 select kernel for ND=%d", ND);
+#define CC_SMP16(NDV, NS)                                                                                         \
+  hipLaunchKernelGGL((knn_sample16_kernel<NDV, NS>), dim3((unsigned)nwaves), dim3(64), 0, stream(), P16, a.norms, a.x, \
+                     a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, s, S, NBs, bstride, out_min)
+  if (NSET == 2) {
+    switch (ND) {
+      case 1: CC_SMP16(1, 2); break;
+      case 2: CC_SMP16(2, 2); break;
+      case 4: CC_SMP16(4, 2); break;
+      default: CC_REQUIRE(false, "knn: no fp16 sample kernel for ND=%d", ND);
+    }
+  } else {
+    switch (ND) {
+      case 1: CC_SMP16(1, 4); break;
+      case 2: CC_SMP16(2, 4); break;
+      case 4: CC_SMP16(4, 4); break;
+      default: CC_REQUIRE(false, "knn: no fp16 sample kernel for ND=%d", ND);
+    }
   }
-#undef CC_SEL16
+#undef CC_SMP16
   CC_HIP(hipGetLastError());
   return CC_OK;
 }
@@ -1758,11 +1786,11 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
 #ifndef CC_KNN_SAMPLE
 #define CC_KNN_SAMPLE 8
 #endif
-  const int SAMPLE = CC_KNN_SAMPLE;
+  const int SAMPLE = ws.sample_stride > 0 ? ws.sample_stride : CC_KNN_SAMPLE;
 #ifndef CC_KNN_MIN_M
-#define CC_KNN_MIN_M (128 / CC_KNN_SAMPLE)   // 16 at SAMPLE = 8: m >= k for k <= 16, so the sampled points alone fill the list
+#define CC_KNN_MIN_M 16   // m >= k for k <= 16, so the sampled points alone fill the list
 #endif
-  const int m_min = CC_KNN_MIN_M, m_k = (3 * k + SAMPLE - 1) / SAMPLE;   // SAMPLE·m >= max(128, 3k) expected below T
+  const int m_min = CC_KNN_MIN_M, m_k = (3 * k + SAMPLE - 1) / SAMPLE;   // SAMPLE·m >= 3k expected below T
   const int m = m_k > m_min ? m_k : m_min;
   // Route 1a pays ~50 us per block while its lists fill (every block overflows them), 1-4 ms even at
   // N = 1000; 1b has no such phase, so it takes everything from 8 sampled blocks up, and inputs that
@@ -1779,7 +1807,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
                                        N >= (int64_t)CC_KNN_MIN_SBLK * SAMPLE * m && k <= CC_KNN_SAMPLED_MAXK);
 
   DevBuf &P = ws.P, &P16 = ws.P16, &norms = ws.norms, &maxn = ws.maxn, &keys = ws.keys, &cnts = ws.cnts,
-         &bound = ws.bound, &skeys = ws.skeys, &scnts = ws.scnts, &Tq = ws.Tq, &cbuf = ws.cbuf, &ccur = ws.ccur,
+         &bound = ws.bound, &skeys = ws.skeys, &scnts = ws.scnts, &smin = ws.smin, &Tq = ws.Tq, &cbuf = ws.cbuf, &ccur = ws.ccur,
          &oidx = ws.oidx, &odist = ws.odist, &nflag = ws.nflag, &flagged = ws.flagged, &bnd_d = ws.bnd_d,
          &bnd_i = ws.bnd_i, &partial = ws.partial, &mu = ws.mu;
   int rc;
@@ -1834,27 +1862,6 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
     int64_t NBs = NB;
     const float *Tptr = nullptr;
     if (sampled) {
-      // 1b-i: threshold from the sample (select with m-entry lists over every 8th block)
-#ifndef CC_KNN_SAMPLE_SPARE
-#define CC_KNN_SAMPLE_SPARE 32
-#endif
-      const int KPS = (int)round_up(m, 16), CAPS = KPS + CC_KNN_SAMPLE_SPARE;
-      // the sample pass is split over candidate ranges too, so that its (long-lived, list-carrying)
-      // waves fill the chip in several short rounds instead of one round plus a nearly empty one
-#ifndef CC_KNN_SAMPLE_ROUNDS
-#define CC_KNN_SAMPLE_ROUNDS 1
-#endif
-      int SS = 1;
-      int64_t NBss = NB;
-      {
-        const size_t sl = sizeof(u64) * 32 * (size_t)(CAPS + 1) + 32 * 8;
-        int64_t wpc = (int64_t)(160 * 1024 / sl);
-        if (wpc > 12) wpc = 12;
-        const int want = (int)ceil_div(CC_KNN_SAMPLE_ROUNDS * 256 * wpc, tiles);
-        make_splits(NB, want > 8 ? 8 : want, &SS, &NBss);
-        while (SS > 1 && NBss / SAMPLE < 4 * m) { --SS; NBss = ceil_div(NB, SS); }   // keep >= 4m sampled blocks per range
-        if (SS == 1) NBss = NB;
-      }
       if ((rc = Tq.alloc(sizeof(float) * (size_t)n_q))) return rc;
       // both passes of 1b run on the fp16 matrix cores when the centred data's scale keeps s, s² and the
       // scaled norms well inside the fp32/fp16 ranges; otherwise on the fp32 ones
@@ -1880,39 +1887,86 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
         hipLaunchKernelGGL(knn_pack16_kernel, dim3((unsigned)ceil_div(units, 256)), dim3(256), 0, stream(), d_x,
                            mu.as<float>(), norms.as<float>(), N, d, ND16, NB, scale16, P16.as<h8>());
       }
+      // 1b-i: threshold from the sample (every SAMPLE-th candidate block)
       if (collect_all) {
         hipLaunchKernelGGL(knn_fill_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(), Tq.as<float>(),
                            n_q, INFINITY);
+      } else if (scale16 > 0.f && ws.use_fp16_select && ND16 <= 4) {   // ND = 8 (d > 64): fp32 lists below
+        // slot minima (knn_sample16_kernel): T = the m-th smallest of 32·NSET·SS minima per query.  One wave per
+        // 32 queries and candidate range; what counts is how evenly the waves load the 1024 SIMDs: the candidate
+        // range is split so that the per-SIMD wave count rounds up by little (3125 whole-range waves would put 4 on
+        // some SIMDs and 3 on the rest), at a fixed cost per wave of ~8 tiles.
+        const int NSET = m <= 20 ? 2 : 4;
+        int SS = 1;
+        int64_t NBss = NB;
+        {
+          int want = 1;
+          if (ws.sample_splits > 0) {
+            want = ws.sample_splits;
+          } else {
+            double best = 1e300;
+            for (int cand = 1; cand <= 8; ++cand) {
+              const double cost = (double)ceil_div(tiles * cand, 1024) * ((double)ceil_div(NB, (int64_t)cand * SAMPLE) + 8.0);
+              if (cost < best * 0.97) { best = cost; want = cand; }
+            }
+          }
+          if (want * NSET > 32) want = 32 / NSET;
+          make_splits(NB, want, &SS, &NBss);
+          if (SS == 1) NBss = NB;
+        }
+        const int nslots = 32 * NSET * SS;
+        if ((rc = smin.alloc(sizeof(float) * (size_t)n_q * (size_t)nslots))) return rc;
+        if ((rc = run_sample16(ND16, NSET, P16.as<h8>(), sa, scale16, SS, NBss, SAMPLE, smin.as<float>()))) return rc;
+        hipLaunchKernelGGL(knn_slot_threshold_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), 0, stream(),
+                           smin.as<float>(), n_q, nslots, m, Tq.as<float>());
       } else {
+        // fp32 route: select with m-entry LDS lists over the sampled blocks, T = the m-th best of the sample
+#ifndef CC_KNN_SAMPLE_SPARE
+#define CC_KNN_SAMPLE_SPARE 32
+#endif
+        const int KPS = (int)round_up(m, 16), CAPS = KPS + CC_KNN_SAMPLE_SPARE;
+        // split over candidate ranges too, so that the (long-lived, list-carrying) waves fill the chip
+        int SS = 1;
+        int64_t NBss = NB;
+        {
+          const size_t sl = sizeof(u64) * 32 * (size_t)(CAPS + 1) + 32 * 8;
+          int64_t wpc = (int64_t)(160 * 1024 / sl);
+          if (wpc > 12) wpc = 12;
+          const int want = (int)ceil_div(256 * wpc, tiles);
+          make_splits(NB, want > 8 ? 8 : want, &SS, &NBss);
+          while (SS > 1 && NBss / SAMPLE < 4 * m) { --SS; NBss = ceil_div(NB, SS); }   // keep >= 4m sampled blocks per range
+          if (SS == 1) NBss = NB;
+        }
         if ((rc = skeys.alloc(sizeof(u64) * (size_t)(n_q * KPS) * (size_t)SS))) return rc;
         if ((rc = scnts.alloc(sizeof(int) * (size_t)n_q * (size_t)SS))) return rc;
-        if (scale16 > 0.f && ws.use_fp16_select && ND16 <= 4) {   // ND = 8 (d > 64) spills: fp32 select there
-          if ((rc = run_select16(ND16, P16.as<h8>(), sa, scale16, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(),
-                                 scnts.as<int>())))
-            return rc;
-        } else {
-          if ((rc = pack_fp32_panels())) return rc;
-          if ((rc = run_select(NG, sa, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) return rc;
-        }
+        if ((rc = pack_fp32_panels())) return rc;
+        if ((rc = run_select(NG, sa, KPS, CAPS, SS, NBss, SAMPLE, skeys.as<u64>(), scnts.as<int>()))) return rc;
         hipLaunchKernelGGL(knn_threshold_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(),
                            skeys.as<u64>(), scnts.as<int>(), n_q, SS, KPS, m, Tq.as<float>());
       }
-      // 1b-ii: collect over all candidates, 8 splits (one per XCD) or fewer for short scans
-      // 8 splits = one per XCD (its slice of the panels stays in that XCD's L2).  Workgroups all take the same
-      // time, so what counts is whole rounds over the 768 resident slots (3 per CU): when 8 splits spill a few
-      // workgroups into an extra round (a 12.5k-query shard: 784), fewer, longer splits that fit the rounds win
-      // even though they lose the XCD affinity (measured with the CC_KNN_OPT_COLLECT_SPLITS override, tools/knn_split_sweep.sh).
+      // 1b-ii: collect over all candidates, split into S candidate ranges.  A multiple of 8 keeps one XCD on one
+      // slice of the panels (workgroup i runs on XCD i % 8 and takes range i % S), which stays in that XCD's L2.
+      // Workgroups all take about the same time, so what counts is whole rounds over the 768 resident slots
+      // (3 per CU): 8 splits of a 100k-query search are 4.07 rounds = 5 (the last one nearly empty), 32 shorter
+      // ones 16.3 = 17 quarter-length rounds; fewer, longer splits that fit the rounds can win for short shards
+      // even though they lose the XCD affinity (x 1.15, measured with the CC_KNN_OPT_COLLECT_SPLITS override,
+      // tools/knn_split_sweep.sh).  Each workgroup pays ~4 blocks' worth of set-up.
+      const bool coarse = scale16 > 0.f && ws.use_coarse_collect && !collect_all;
+      // 256 queries per workgroup once 8 ranges of them still fill a round
+      const int QW = (coarse && ND16 <= 4 && ceil_div(n_q, 256) * 8 >= 768) ? 2 : 1;
       {
         int want = 8;
         const int forced = ws.collect_splits;
         if (forced > 0) {
           want = forced;
         } else {
-          const int64_t wgs = ceil_div(n_q, 128), slots = 768;
+          const int64_t wgs = ceil_div(n_q, 128 * QW), slots = 768;
           double best = 1e300;
-          for (int cand = 8; cand >= 5; --cand) {
-            const double cost = (double)ceil_div(wgs * cand, slots) * (double)ceil_div(NB, cand) * (cand == 8 ? 1.0 : 1.15);
-            if (cost < best) { best = cost; want = cand; }
+          for (int cand : {8, 7, 6, 5, 16, 24, 32}) {
+            if (cand > 8 && (!coarse || NB / cand < 64)) continue;
+            const double cost = (double)ceil_div(wgs * cand, slots) * ((double)ceil_div(NB, cand) + 4.0) *
+                                (cand % 8 == 0 ? 1.0 : 1.15);
+            if (cost < best * 0.97) { best = cost; want = cand; }
           }
         }
         make_splits(NB, want, &S, &NBs);
@@ -1921,9 +1975,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
       if ((rc = ccur.alloc(sizeof(int) * (size_t)n_q))) return rc;
       CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
       if (scale16 > 0.f) {
-        if (ws.use_coarse_collect && !collect_all) {
-          // 256 queries per workgroup once that still leaves a full round of workgroups over the chip's 768 slots
-          const int QW = (ND16 <= 4 && ceil_div(n_q, 256) * S >= 768) ? 2 : 1;
+        if (coarse) {
           if ((rc = run_collect16c(ND16, QW, P16.as<h8>(), sa, maxn.as<unsigned>(), Tq.as<float>(), scale16, S, NBs, col_cap,
                                    cbuf.as<u64>(), ccur.as<int>())))
             return rc;
@@ -2097,8 +2149,16 @@ int cc_knn_set_option(void *knn, int option, int value) {
     case CC_KNN_OPT_FP64_PREFILTER: ws->use_fp64_prefilter = value != 0; break;
     case CC_KNN_OPT_COARSE_COLLECT: ws->use_coarse_collect = value != 0; break;
     case CC_KNN_OPT_COLLECT_SPLITS:
-      CC_REQUIRE(value >= 0 && value <= 64, "collect splits %d outside [0, 64]", value);
+      CC_REQUIRE(value >= 0 && value <= 1024, "collect splits %d outside [0, 1024]", value);
       ws->collect_splits = value;
+      break;
+    case CC_KNN_OPT_SAMPLE_SPLITS:
+      CC_REQUIRE(value >= 0 && value <= 16, "sample splits %d outside [0, 16]", value);
+      ws->sample_splits = value;
+      break;
+    case CC_KNN_OPT_SAMPLE_STRIDE:
+      CC_REQUIRE(value >= 0 && value <= 64, "sample stride %d outside [0, 64]", value);
+      ws->sample_stride = value;
       break;
     default: CC_REQUIRE(false, "unknown kNN option %d", option);
   }

@@ -17,6 +17,10 @@ if os.environ.get('CC_FULL'):
     _lib.lib().cc_knn_force_full_select(1)   # route 1a whatever the size
 if os.environ.get('CC_KNN_COLLECT_SPLITS'):  # sweep knob (tools/knn_split_sweep.sh): an option of the workspace, not an env read in the library
     _lib.check(_lib.lib().cc_knn_set_option(None, 5, int(os.environ['CC_KNN_COLLECT_SPLITS'])))
+if os.environ.get('CC_KNN_SAMPLE_SPLITS'):
+    _lib.check(_lib.lib().cc_knn_set_option(None, 7, int(os.environ['CC_KNN_SAMPLE_SPLITS'])))
+if os.environ.get('CC_KNN_SAMPLE_STRIDE'):
+    _lib.check(_lib.lib().cc_knn_set_option(None, 8, int(os.environ['CC_KNN_SAMPLE_STRIDE'])))
 x = torch.rand((n, d), device='cuda'); torch.cuda.synchronize()
 knn_graph_device(x.data_ptr(), n, d, k, 0, nq)
 _lib.profile_enable(True); _lib.profile_reset()
