@@ -614,6 +614,20 @@ __device__ __forceinline__ void split3(float v, _Float16 *a, _Float16 *b, _Float
   *c = (_Float16)(r1 - (float)*b);
 }
 
+// query-side norm unit of lane half h for the value v (already divided by 256): {256, 256, 256, v_a, v_b, v_c, 0, 0}
+__device__ __forceinline__ h8 query_norm_unit(float v, int h) {
+  h8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (_Float16)0.f;
+  if (h == 0) {
+    _Float16 a, b, c;
+    split3(v, &a, &b, &c);
+    const _Float16 k256 = (_Float16)256.f;
+    o[0] = k256; o[1] = k256; o[2] = k256; o[3] = a; o[4] = b; o[5] = c;
+  }
+  return o;
+}
+
 // one 16-byte unit (8 halfs) of operand data for row `i` of x, K-step t, lane half h:
 //   t < ND          hi parts of (fac · y[16t + 8h + j]),  j = 0..7
 //   t == ND         norm step: h == 0 -> {n_a, n_b, n_c, 256, 256, 256, 0, 0} (candidate side) or
@@ -957,7 +971,14 @@ __global__ __launch_bounds__(256, CC_KNN_C16_MINW) void knn_collect16_kernel(
 // |qh_i·ch_i − s²q_i c_i| <= (2^-10 + 2^-22) s²|q_i c_i| + 2^-25·2^7·2 ; summed (Cauchy-Schwarz, 2|q||c| <= |q|²+|c|²)
 // and doubled for the −2q·c factor: <= 2^-10·1.001·s²(‖q‖² + ‖c‖²) + d·2^-16, plus 16(ND+1) fp32 roundings on terms that
 // sum to <= 3 s²(‖q‖² + ‖c‖²) (2^-18 relative).  Used: 2^-9 · s²(‖q−μ‖² + max‖c−μ‖²) + d·2^-15  (>= 1.9x the bound).
-constexpr int C16C_CB = 4;   // candidate blocks per LDS stage (a block's hi + norm units: (ND + 1) KiB)
+//
+// The test itself costs one instruction per pair: the query's norm slot of the operand carries s²‖q−μ‖² − Ts (Ts = the
+// scaled threshold + bound, capped at 1.5·2^23, above any scaled distance at d <= 128 — the three-piece fp16 split holds
+// it to 2^-33), so the accumulator IS (coarse distance − Ts) and a pair passes when its sign bit is set.  The 16 sign
+// bits of a lane's accumulators are shifted into one mask register (v_alignbit), lanes with a non-zero mask park their
+// pairs in rounds (one pair per lane and round), and a tile none of whose 1024 signs is set is rejected by an OR tree
+// when hits are rare.  The fp32 rounding of the shifted accumulation (a few units at 2^-2) disappears in the spare
+// half of the bound (2^-10 · s²·norms: thousands of units).  Masked pairs (self, padding) are set to +0.
 
 struct WaveBufC {
   unsigned *cand;   // [COL_WB] candidate index
@@ -1002,10 +1023,80 @@ __device__ __forceinline__ void wavebufc_flush(WaveBufC &wb, const float *__rest
   wb.n = 0;
 }
 
+#define CC_KNN_GLDS16(src, dst)                                                             \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src),   \
+                                   (void __attribute__((address_space(3))) *)(dst), 16, 0, 0)
+
+// the passing pairs of one 32 x 32 tile (acc = coarse distance − threshold: sign bit set = pass) into the wave's
+// parking buffer; g = the wave's query group the tile belongs to
+__device__ __forceinline__ void collect16c_tile(f32x16 &acc, int64_t b, int64_t NB, int64_t self_blk, unsigned self_bit,
+                                                unsigned tail_vm, int min_first, int g, WaveBufC &wb,
+                                                const float *__restrict__ x, int d, int vec, int64_t q_begin,
+                                                const float *__restrict__ T, u64 *__restrict__ buf,
+                                                int *__restrict__ cursor, int64_t q0, int64_t n_q, int cap, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  if (__any(b == self_blk) || b == NB - 1) {
+    // masked pairs (the query itself, padding rows of the last block) become +0; plain bit arithmetic on a per-lane
+    // mask, so that no per-entry lane masks live in scalar registers across the loop
+    const unsigned km = (b == self_blk ? self_bit : 0u) | (b == NB - 1 ? ~tail_vm & 0xffffu : 0u);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = __uint_as_float(__float_as_uint(acc[e]) & (((km >> e) & 1u) - 1u));
+  }
+  if (min_first) {
+    // few pairs pass per tile when the candidate set is large (1024 * 8m / N expected: 0.13 at N = 1M): an OR tree
+    // over the 16 accumulators + one ballot of its sign rejects the whole tile
+    unsigned o = __float_as_uint(acc[0]) | __float_as_uint(acc[1]) | __float_as_uint(acc[2]);
+    o |= __float_as_uint(acc[3]) | __float_as_uint(acc[4]);
+    o |= __float_as_uint(acc[5]) | __float_as_uint(acc[6]);
+    o |= __float_as_uint(acc[7]) | __float_as_uint(acc[8]);
+    o |= __float_as_uint(acc[9]) | __float_as_uint(acc[10]);
+    o |= __float_as_uint(acc[11]) | __float_as_uint(acc[12]);
+    o |= __float_as_uint(acc[13]) | __float_as_uint(acc[14]);
+    o |= __float_as_uint(acc[15]);
+    if (!__any((int)o < 0)) return;
+  }
+  // hm bit (15 − e) = sign of acc[e]
+  unsigned hm = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) hm = __builtin_amdgcn_alignbit(hm, __float_as_uint(acc[e]), 31);
+  const unsigned cbase = (unsigned)(b * 32) + 4 * h;
+  while (true) {   // one parked pair per lane and round; wave-uniform trip count
+    const unsigned long long lm = __ballot(hm != 0);
+    if (!lm) break;
+    const int cnt = __builtin_popcountll(lm);
+    if (wb.n + cnt > COL_WB) wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
+    if (hm != 0) {
+      const int e = 15 - (__builtin_ffs((int)hm) - 1);
+      const int pos = wb.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
+      wb.cand[pos] = cbase + (e & 3) + 8 * (e >> 2);
+      wb.qr[pos] = g * 32 + r;
+      hm &= hm - 1;
+    }
+    wb.n += cnt;
+  }
+}
+
 // QW = 32-query groups per wave: 2 makes a workgroup own 256 queries, so a candidate panel crosses the fabric and LDS
-// once per 256 queries instead of 128 (at N = 1M the panels no longer fit the L2s: 152 GB of panel reads for one
-// rank's search with QW = 1) and every fragment read feeds two MFMA chains; 1 keeps more workgroups for short query
-// ranges.
+// once per 256 queries instead of 128 and every fragment read feeds two MFMA chains; 1 keeps more workgroups for
+// short query ranges.  The hi + norm units of CB candidate blocks form a stage (8-12 KiB); stages reach LDS by
+// LDS-DMA (global_load_lds: a unit = 64 lanes x 16 bytes is contiguous in the panel and in LDS) through a ring of
+// C16C_NSTAGE buffers, the DMA running NSTAGE - 1 stages ahead of the MFMAs with counted vmcnt waits (at N = 1M
+// a quarter of the panel reads miss the L2 and take > 1 us: one stage ahead left the workgroup waiting at every
+// barrier), one barrier per stage.  A stage's fragments are read at its start, and the QW MFMA chains of a block go
+// back to back into separate accumulators so that the sign tests of one group run under the MFMAs of the next.
+constexpr int C16C_NSTAGE = 4;
+template <int ND>
+struct C16C {
+  static constexpr int CB = ND == 1 ? 4 : ND == 2 ? 4 : ND == 4 ? 2 : 1;   // candidate blocks per stage
+  static constexpr int HU = (ND + 1) * 64;                                  // hi + norm units (16 B) of a block
+  static constexpr int STAGE_U = CB * HU;
+  static constexpr int NU = CB * (ND + 1);                                  // 64-lane unit rows per stage
+  static constexpr int DPS = (NU + 3) / 4;                                  // DMA instructions per wave and stage
+  static constexpr size_t lds_bytes() {
+    return sizeof(h8) * C16C_NSTAGE * STAGE_U + (sizeof(unsigned) + sizeof(int)) * 4 * COL_WB;
+  }
+};
+
 template <int ND, int QW>
 __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
@@ -1013,54 +1104,74 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     int64_t n_q, int include_self, const float *__restrict__ T, float s, int S, int64_t NBs, int cap,
     u64 *__restrict__ buf, int *__restrict__ cursor, int min_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  using C_ = C16C<ND>;
   constexpr int NT = 2 * ND + 1;             // units per candidate block in the panel
-  constexpr int HU = (ND + 1) * 64;          // hi + norm units of a block: what this kernel stages
-  constexpr int STAGE_U = C16C_CB * HU;
+  constexpr int CB = C_::CB, HU = C_::HU, STAGE_U = C_::STAGE_U, NU = C_::NU, DPS = C_::DPS, NSTAGE = C16C_NSTAGE;
   constexpr int QPW = 32 * QW;               // queries per wave
-  h8 *stage = reinterpret_cast<h8 *>(smem);  // [2][STAGE_U], then the 4 parking buffers
+  h8 *stage = reinterpret_cast<h8 *>(smem);  // [NSTAGE][STAGE_U], then the 4 parking buffers
 
   const int64_t tile = blockIdx.x / S;
   const int split = blockIdx.x % S;
   const int64_t b_lo = split * NBs;
   const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const float s2 = s * s;
   const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
   const int64_t q0 = tile * (4 * QPW) + wave * QPW;
+  const int64_t nstages = (b_hi - b_lo + CB - 1) / CB;
+
+  // every wave issues DPS instructions per stage (the vmcnt arithmetic needs equal counts): unit rows beyond NU
+  // repeat the last one, blocks beyond the range repeat its last block
+  auto issue = [&](int64_t st, int slot) {
+#pragma unroll
+    for (int i = 0; i < DPS; ++i) {
+      int u = wave + 4 * i;
+      u = u < NU ? u : NU - 1;
+      const int cb = u / (ND + 1), t = u - cb * (ND + 1);
+      int64_t b = b_lo + st * CB + cb;
+      b = b < b_hi ? b : b_hi - 1;
+      CC_KNN_GLDS16(P16 + (b * NT + t) * 64 + lane, stage + (slot * STAGE_U + u * 64));
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < NSTAGE - 1; ++p)
+    if (p < nstages) issue(p, p);   // under the set-up below
 
   h8 bqh[QW][ND + 1];
-  float Ts[QW];
   int64_t self_blk[QW];
-  int self_e[QW];
+  unsigned self_bit[QW];
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
     const int64_t ql = q0 + g * 32 + r;
     const bool qvalid = ql < n_q;
     const int64_t q = q_begin + ql;
 #pragma unroll
-    for (int t = 0; t <= ND; ++t)
+    for (int t = 0; t < ND; ++t)
       bqh[g][t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
-    // coarse threshold in the tile's scaled units (see the bound above)
-    Ts[g] = -INFINITY;
+    // norm slot = s²‖q−μ‖² − Ts: the accumulator becomes (coarse distance − threshold), see the bound above
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bqh[g][ND][j] = (_Float16)0.f;
     if (qvalid) {
-      const float nsum = norms[q] + __uint_as_float(maxnorm_bits[0]);
-      Ts[g] = (T[ql] + 1.953125e-3f * nsum) * s2 + (float)d * 3.0517578125e-5f;
+      const float nq = norms[q];
+      const float Ts = fminf((T[ql] + 1.953125e-3f * (nq + __uint_as_float(maxnorm_bits[0]))) * s2 + (float)d * 3.0517578125e-5f,
+                             12582912.0f);
+      bqh[g][ND] = query_norm_unit((nq * s2 - Ts) * (1.0f / 256.0f), h);
     }
     self_blk[g] = -1;
-    self_e[g] = -1;
+    self_bit[g] = 0;
     if (qvalid && !include_self) {
       const int row = (int)(q & 31);
       if (((row >> 2) & 1) == h) {
         self_blk[g] = q >> 5;
-        self_e[g] = (row & 3) | ((row >> 3) << 2);
+        self_bit[g] = 1u << ((row & 3) | ((row >> 3) << 2));
       }
     }
   }
   WaveBufC wb;
-  wb.cand = reinterpret_cast<unsigned *>(smem + sizeof(h8) * 2 * STAGE_U) + wave * COL_WB;
-  wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * 2 * STAGE_U + sizeof(unsigned) * 4 * COL_WB) + wave * COL_WB;
+  wb.cand = reinterpret_cast<unsigned *>(smem + sizeof(h8) * NSTAGE * STAGE_U) + wave * COL_WB;
+  wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * NSTAGE * STAGE_U + sizeof(unsigned) * 4 * COL_WB) + wave * COL_WB;
   wb.n = 0;
 
   unsigned tail_vm = 0xffffu;
@@ -1068,105 +1179,46 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
   for (int e = 0; e < 16; ++e)
     if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
 
-  const int64_t nstages = (b_hi - b_lo + C16C_CB - 1) / C16C_CB;
-  const f32x4 *Pv = reinterpret_cast<const f32x4 *>(P16);
-  f32x4 *stage_v = reinterpret_cast<f32x4 *>(smem);
-  constexpr int NS = (STAGE_U + 255) / 256;
-  int s_cb[NS], s_off[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    int f = i * 256 + tid;
-    f = f < STAGE_U ? f : STAGE_U - 1;
-    s_cb[i] = f / HU;
-    s_off[i] = f - s_cb[i] * HU;
-  }
-  f32x4 rs[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    int64_t b = b_lo + s_cb[i];
-    b = b < b_hi ? b : b_hi - 1;
-    rs[i] = Pv[b * (NT * 64) + s_off[i]];
-  }
-#pragma unroll
-  for (int i = 0; i < NS; ++i) stage_v[s_cb[i] * HU + s_off[i]] = rs[i];
+  // stage 0 must have landed; NSTAGE - 2 later ones may stay in flight
+  if (nstages >= NSTAGE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  int cur = 0;
+  int slot = 0;
   for (int64_t st = 0; st < nstages; ++st) {
-    const bool more = st + 1 < nstages;
-    if (more) {
+    // the slot written now was read one stage ago, and every wave is past that barrier
+    const bool ahead = st + NSTAGE - 1 < nstages;
+    if (ahead) issue(st + NSTAGE - 1, (slot + NSTAGE - 1) % NSTAGE);
+    const h8 *sbuf = stage + slot * STAGE_U + lane;
+    h8 ah[CB][ND + 1];
 #pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        int64_t b = b_lo + (st + 1) * C16C_CB + s_cb[i];
-        b = b < b_hi ? b : b_hi - 1;
-        rs[i] = Pv[b * (NT * 64) + s_off[i]];
-      }
-    }
-    const h8 *sbuf = stage + cur * STAGE_U;
+    for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
-    for (int cb = 0; cb < C16C_CB; ++cb) {
-      const int64_t b = b_lo + st * C16C_CB + cb;
-      if (b < b_hi) {
-        const h8 *sb = sbuf + cb * HU;
-        h8 ah[ND + 1];
+      for (int t = 0; t <= ND; ++t) ah[cb][t] = sbuf[cb * HU + t * 64];
 #pragma unroll
-        for (int t = 0; t <= ND; ++t) ah[t] = sb[t * 64 + lane];
-        const unsigned cbase = (unsigned)(b * 32) + 4 * h;
+    for (int cb = 0; cb < CB; ++cb) {
+      const int64_t b = b_lo + st * CB + cb;
+      if (b < b_hi) {   // workgroup-uniform
+        f32x16 acc[QW];
 #pragma unroll
         for (int g = 0; g < QW; ++g) {
-          f32x16 acc;
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+          for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
 #pragma unroll
-          for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bqh[g][t], acc, 0, 0, 0);
-          if (__any(b == self_blk[g]) || b == NB - 1) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const bool kill = (b == self_blk[g] && e == self_e[g]) || (b == NB - 1 && !((tail_vm >> e) & 1u));
-              acc[e] = kill ? __builtin_nanf("") : acc[e];
-            }
-          }
-          if (min_first) {
-            // few pairs pass per tile when the candidate set is large (1024 * 8m / N expected: 0.13 at N = 1M): one
-            // min3 tree + one ballot rejects the whole tile instead of 16 compare + branch pairs (NaN = killed
-            // entries drop out of fminf)
-            float mn = fminf(fminf(acc[0], acc[1]), acc[2]);
-            mn = fminf(fminf(mn, acc[3]), acc[4]);
-            mn = fminf(fminf(mn, acc[5]), acc[6]);
-            mn = fminf(fminf(mn, acc[7]), acc[8]);
-            mn = fminf(fminf(mn, acc[9]), acc[10]);
-            mn = fminf(fminf(mn, acc[11]), acc[12]);
-            mn = fminf(fminf(mn, acc[13]), acc[14]);
-            mn = fminf(mn, acc[15]);
-            if (!__any(mn <= Ts[g])) continue;
-          }
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const bool pass = acc[e] <= Ts[g];
-            const unsigned long long mask = __ballot(pass);
-            if (mask) {   // wave-uniform
-              const int cnt = __builtin_popcountll(mask);
-              if (wb.n + cnt > COL_WB) wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
-              if (pass) {
-                const int pos = wb.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                      __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                wb.cand[pos] = cbase + (e & 3) + 8 * (e >> 2);
-                wb.qr[pos] = g * 32 + r;
-              }
-              wb.n += cnt;
-            }
-          }
-          __builtin_amdgcn_wave_barrier();
+          for (int t = 0; t <= ND; ++t)
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][t], bqh[g][t], acc[g], 0, 0, 0);
         }
+#pragma unroll
+        for (int g = 0; g < QW; ++g)
+          collect16c_tile(acc[g], b, NB, self_blk[g], self_bit[g], tail_vm, min_first, g, wb, x, d, vec, q_begin, T, buf,
+                          cursor, q0, n_q, cap, lane);
       }
     }
-    if (more) {
-      f32x4 *dbuf = stage_v + (cur ^ 1) * STAGE_U;
-#pragma unroll
-      for (int i = 0; i < NS; ++i) dbuf[s_cb[i] * HU + s_off[i]] = rs[i];
-    }
+    // the next stage's data must have landed (in the tail fewer stages are in flight than the count assumes)
+    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    cur ^= 1;
+    slot = (slot + 1) % NSTAGE;
   }
   wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
 }
@@ -1718,7 +1770,7 @@ static int run_collect16c(int ND, int QW, const h8 *P16, const SelectArgs &a, co
   const int min_first = (1024.0 * (double)(cap / 4) / (double)a.N) < 0.5 ? 1 : 0;
 #define CC_COL16C(NDV, QWV)                                                                                          \
   hipLaunchKernelGGL((knn_collect16c_kernel<NDV, QWV>), dim3((unsigned)nwg), dim3(256),                              \
-                     sizeof(h8) * 2 * C16C_CB * (NDV + 1) * 64 + (sizeof(unsigned) + sizeof(int)) * 4 * COL_WB, stream(), \
+                     C16C<NDV>::lds_bytes(), stream(),                                                                \
                      P16, a.norms, maxnorm_bits, a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, \
                      NBs, cap, buf, cursor, min_first)
   if (QW == 2) {

@@ -69,6 +69,19 @@ def use_coarse_collect(on):
     _lib.check(_lib.lib().cc_knn_set_option(None, 6, 1 if on else 0))
 
 
+def use_fp16_sample(on):
+    """Stage 1b sample pass as slot minima on the fp16 matrix cores (default) or as list select on the fp32 ones;
+    same results, different threshold and speed (CC_KNN_OPT_FP16_SELECT)."""
+    _lib.check(_lib.lib().cc_knn_set_option(None, 3, 1 if on else 0))
+
+
+def set_sample_layout(splits=0, stride=0):
+    """Tuning / test hook: candidate ranges of the fp16 sample pass and the sampling stride in candidate blocks
+    (0 = chosen by the library).  Results never depend on them (CC_KNN_OPT_SAMPLE_SPLITS / _STRIDE)."""
+    _lib.check(_lib.lib().cc_knn_set_option(None, 7, int(splits)))
+    _lib.check(_lib.lib().cc_knn_set_option(None, 8, int(stride)))
+
+
 def use_fp64_prefilter(on):
     """Stage 3: narrow each uncertified query's candidates with a float64 matrix-core pass (default) before
     the exact evaluation, or scan all candidates; same results, different speed."""

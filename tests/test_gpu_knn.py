@@ -171,6 +171,35 @@ def test_coarse_and_three_product_collect_agree(hip, oracle_built, kind):
         assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (kind, coarse)
 
 
+@pytest.mark.parametrize('n,d,k', [(600, 16, 15), (5000, 64, 15), (5000, 33, 50), (7000, 64, 128), (3000, 7, 100)])
+def test_sample_layouts_never_change_the_result(hip, oracle_built, n, d, k):
+    """The threshold of stage 1b is the m-th smallest of the per-slot minima of the sampled tiles: 64 slots per query
+    (128 for m > 20), times the candidate ranges the pass is split over.  Whatever the stride, the number of ranges
+    or the engine (fp32 list select with the option off), the neighbour lists are the oracle's; a looser or tighter
+    threshold only moves work between the stages."""
+    rng = np.random.default_rng(n * 7 + d + k)
+    x = rng.random((n, d), dtype=np.float32)
+    x[rng.choice(n, n // 25, replace=False)] = x[rng.choice(n, n // 25)]
+    want_i, want_d = ko.knn(x, k)
+    try:
+        for splits, stride in [(0, 0), (1, 8), (3, 8), (8, 8), (16, 1), (2, 2), (1, 5), (4, 16)]:
+            hipknn.set_sample_layout(splits, stride)
+            idx, dist = cc.knn_graph(x, k)
+            assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (splits, stride)
+        hipknn.set_sample_layout(0, 0)
+        idx0, _ = cc.knn_graph(x, k)
+        fb_slots = hipknn.last_fallback_count()
+        hipknn.use_fp16_sample(False)
+        idx, dist = cc.knn_graph(x, k)
+        assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d)
+        # the slot-minima threshold is looser than the exact m-th best of the sample, never tighter: it cannot send
+        # more queries to the float64 stage for lack of candidates
+        assert fb_slots <= hipknn.last_fallback_count() + n // 100
+    finally:
+        hipknn.set_sample_layout(0, 0)
+        hipknn.use_fp16_sample(True)
+
+
 def test_near_ties_below_fp32_resolution(hip, oracle_built):
     # neighbours whose distances differ by far less than the fp32 error of stage 1
     rng = np.random.default_rng(6)
