@@ -358,17 +358,21 @@ def main():
         ksel = [prof[c] for c in ('knn_pack', 'knn_select', 'knn_rerank', 'knn_fallback')]
         knn_ms = sum(v['ms'] for v in ksel) / args.steps
         if knn_ms > 0:
-            # algorithmic work of the search: 2 * queries * candidates * d; it runs as three fp16 products
-            # per algorithmic product on the fp16 matrix cores (hi/lo split), plus the float64 re-rank
+            # algorithmic work of the search: 2 * queries * candidates * d.  Executed on the fp16 matrix
+            # cores: the collect pass = ONE fp16 product per pair (hi x hi) + the norm step, ND + 1 MFMA K-steps of 16
+            # over all candidates; the sample pass = the three-product form, 3 ND + 1 K-steps, over every 8th block
             knn_flop = 2.0 * (hi - lo) * args.cells * args.latent
             ktf = knn_flop / (knn_ms * 1e-3) / 1e12
-            line['roofline_knn'] = {'kernel': 'knn_select16 + knn_collect16 + knn_merge + knn_rerank (per step)',
+            nd = -(-args.latent // 16)
+            executed = 16.0 * ((nd + 1) + (3 * nd + 1) / 8.0) / args.latent
+            line['roofline_knn'] = {'kernel': 'knn_sample16 + knn_collect16c + knn_merge + knn_rerank (per step)',
                                     'bound': 'mfma', 'achieved': ktf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                    'frac': ktf / PEAK_F16_MFMA_TFLOPS, 'executed_fp16_tflops': 3.375 * ktf,
+                                    'frac': ktf / PEAK_F16_MFMA_TFLOPS, 'executed_fp16_tflops': executed * ktf,
                                     'ms_per_step': knn_ms, 'flop_per_step': knn_flop, 'traffic': None,
-                                    'note': 'achieved = algorithmic 2*q*c*d FLOP / stage time; the collect executes 3 fp16 '
-                                            'products per algorithmic one over all candidates and the sample pass 1/8 more '
-                                            '(x3.375); selection (VALU/LDS) shares the time'}
+                                    'note': 'achieved = algorithmic 2*q*c*d FLOP / stage time; executed = x%.3f (collect: '
+                                            'one fp16 product + norm step over all candidates, sample: three-product form '
+                                            'over 1/8 of them); parking and re-checking the passing pairs (VALU/LDS) shares '
+                                            'the time' % executed}
         gather = prof['gather']
         if gather['ms'] > 0:
             gbs = gather['work'] / (gather['ms'] * 1e-3) / 1e9

@@ -2201,7 +2201,7 @@ int cc_knn_set_option(void *knn, int option, int value) {
     case CC_KNN_OPT_FP64_PREFILTER: ws->use_fp64_prefilter = value != 0; break;
     case CC_KNN_OPT_COARSE_COLLECT: ws->use_coarse_collect = value != 0; break;
     case CC_KNN_OPT_COLLECT_SPLITS:
-      CC_REQUIRE(value >= 0 && value <= 1024, "collect splits %d outside [0, 1024]", value);
+      CC_REQUIRE(value >= 0 && value <= 64, "collect splits %d outside [0, 64]", value);
       ws->collect_splits = value;
       break;
     case CC_KNN_OPT_SAMPLE_SPLITS:
