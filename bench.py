@@ -327,6 +327,26 @@ def main():
         stages = {k: {'launches': v['launches'], 'ms_per_step': v['ms'] / args.steps,
                       'rate': (v['work'] / (v['ms'] * 1e-3)) if v['ms'] > 0 else 0.0}
                   for k, v in prof.items() if v['launches']}
+        w0 = int(args.genes * 0.1) if args.arch == 'cont' else 1000
+        shape = f'x[B x {args.genes}] @ K1[{args.genes} x {w0}]'
+        if args.dtype != 'f32':
+            # fp16 matrix cores: `f16x2` executes two fp16 products per algorithmic product (W = W_hi + W_lo)
+            mult = 2.0 if args.dtype == 'f16x2' else 1.0
+            roofline = {'kernel': f'gemm16_kernel (encoder layer 1, {shape}, {args.dtype})', 'bound': 'mfma',
+                        'achieved': achieved * mult, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': achieved * mult / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
+                        'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch * mult,
+                        'note': 'executed fp16 products; the algorithmic rate is achieved / %g' % mult}
+        else:
+            roofline = {'kernel': ('spmm_bias_act_kernel<1> (encoder layer 1 over the non-zeros of x, fp32 vector FMAs)'
+                                   if args.sparse else f'gemm_bias_act_kernel<1> (encoder layer 1, {shape})'),
+                        'bound': 'valu' if args.sparse else 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS,
+                        'traffic': None if args.sparse else traffic,
+                        'traffic_note': f'REPLAYED, not measured in this run: bytes per launch of the dominant kernel, '
+                                        f'2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes of the same command '
+                                        f'(profiles/{TRAFFIC_PROFILE}); algorithmic minimum 1.45e9 for the dense kernel',
+                        'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch}
         line = {
             'metric': baseline_metric(), 'value': args.cells * args.steps / elapsed,
             'unit': 'cells/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -338,15 +358,7 @@ def main():
                        'cells': args.cells, 'genes': args.genes, 'latent': args.latent, 'k': args.k,
                        'arch': args.arch, 'parallelism': f'cells sharded over {world} GPU(s), 1 all-gather/step',
                        'knn_fallback_queries_rank0': int(_lib.lib().cc_knn_last_fallback_count())},
-            'roofline': {'kernel': ('spmm_bias_act_kernel<1> (encoder layer 1 over the non-zeros of x, fp32 vector FMAs)'
-                                    if args.sparse else
-                                    'gemm_bias_act_kernel<1> (encoder layer 1, x[B x 30000] @ K1[30000 x 3000])'),
-                         'bound': 'valu' if args.sparse else 'mfma', 'achieved': achieved, 'peak': PEAK_F32_MFMA_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': achieved / PEAK_F32_MFMA_TFLOPS, 'traffic': traffic,
-                         'traffic_note': f'REPLAYED, not measured in this run: bytes per launch of the dominant kernel, '
-                                         f'2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes of the same command '
-                                         f'(profiles/{TRAFFIC_PROFILE}); algorithmic minimum 1.45e9 for the dense kernel',
-                         'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch},
+            'roofline': roofline,
             'stages_rank0': stages,
         }
         if alt is not None:
