@@ -690,7 +690,7 @@ __global__ void knn_pack16_kernel(const float *__restrict__ x, const float *__re
 // insertion, needs no LDS, and leaves the pass bound by its MFMAs and fragment loads.  Arithmetic: the 3·ND + 1
 // products of the fp16 split (hi·hi + hi·lo + lo·hi), scaled by s² (a power of two) and unscaled exactly on the
 // way out.
-template <int ND, int NSET>
+template <int ND, int NSET, int QW>
 __global__ __launch_bounds__(64) void knn_sample16_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const float *__restrict__ x,
     const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
@@ -702,24 +702,30 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
   const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
   const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
-  const int64_t ql = tile * 32 + r;
-  const bool qvalid = ql < n_q;
-  const int64_t q = q_begin + ql;
   const float s2 = s * s, inv_s2 = 1.0f / s2;
 
-  h8 bqh[ND + 1], bql[ND];
+  // QW query groups of 32 share every candidate fragment (half the fragment traffic per MFMA when QW = 2)
+  h8 bqh[QW][ND + 1], bql[QW][ND];
+  int64_t self_blk[QW];
+  unsigned self_bit[QW];
 #pragma unroll
-  for (int t = 0; t <= ND; ++t) bqh[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
+  for (int g = 0; g < QW; ++g) {
+    const int64_t ql = (tile * QW + g) * 32 + r;
+    const bool qvalid = ql < n_q;
+    const int64_t q = q_begin + ql;
 #pragma unroll
-  for (int t = 0; t < ND; ++t) bql[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, ND + 1 + t, h, -2.0f * s, 0.f, true);
-
-  int64_t self_blk = -1;
-  int self_e = -1;
-  if (qvalid && !include_self) {
-    const int row = (int)(q & 31);
-    if (((row >> 2) & 1) == h) {
-      self_blk = q >> 5;
-      self_e = (row & 3) | ((row >> 3) << 2);
+    for (int t = 0; t <= ND; ++t)
+      bqh[g][t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
+#pragma unroll
+    for (int t = 0; t < ND; ++t) bql[g][t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, ND + 1 + t, h, -2.0f * s, 0.f, true);
+    self_blk[g] = -1;
+    self_bit[g] = 0;
+    if (qvalid && !include_self) {
+      const int row = (int)(q & 31);
+      if (((row >> 2) & 1) == h) {
+        self_blk[g] = q >> 5;
+        self_bit[g] = 1u << ((row & 3) | ((row >> 3) << 2));
+      }
     }
   }
   unsigned tail_vm = 0xffffu;
@@ -727,11 +733,13 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
   for (int e = 0; e < 16; ++e)
     if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
 
-  f32x16 mn[NSET];
+  f32x16 mn[QW][NSET];
 #pragma unroll
-  for (int u = 0; u < NSET; ++u)
+  for (int g = 0; g < QW; ++g)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) mn[u][e] = INFINITY;
+    for (int u = 0; u < NSET; ++u)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) mn[g][u][e] = INFINITY;
 
   // two register sets of candidate operands, ping-pong: the next sampled block loads while this one computes
   h8 ah[2][ND + 1], al[2][ND];
@@ -756,39 +764,44 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
 #pragma unroll
           for (int t = 0; t < ND; ++t) al[nxt][t] = pb[(ND + 1 + t) * 64];
         }
-        f32x16 acc;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        for (int g = 0; g < QW; ++g) {
+          f32x16 acc;
 #pragma unroll
-        for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bqh[t], acc, 0, 0, 0);
+          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
-        for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bql[t], acc, 0, 0, 0);
+          for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bqh[g][t], acc, 0, 0, 0);
 #pragma unroll
-        for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], bqh[t], acc, 0, 0, 0);
-        if (__any(b == self_blk) || b == NB - 1) {
+          for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bql[g][t], acc, 0, 0, 0);
 #pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const bool kill = (b == self_blk && e == self_e) || (b == NB - 1 && !((tail_vm >> e) & 1u));
-            acc[e] = kill ? INFINITY : acc[e];
+          for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], bqh[g][t], acc, 0, 0, 0);
+          if (__any(b == self_blk[g]) || b == NB - 1) {
+            const unsigned km = (b == self_blk[g] ? self_bit[g] : 0u) | (b == NB - 1 ? ~tail_vm & 0xffffu : 0u);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] = ((km >> e) & 1u) ? INFINITY : acc[e];
           }
-        }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) asm("v_min_f32 %0, %1, %2" : "=v"(mn[u][e]) : "v"(mn[u][e]), "v"(acc[e]));
+          for (int e = 0; e < 16; ++e) asm("v_min_f32 %0, %1, %2" : "=v"(mn[g][u][e]) : "v"(mn[g][u][e]), "v"(acc[e]));
+        }
       }
     }
   }
-  if (qvalid) {
-    // slot order inside a query's G values does not matter to the consumer
-    f32x4 *dst = reinterpret_cast<f32x4 *>(out_min + ((ql * S + split) * NSET * 32 + h * 16));
 #pragma unroll
-    for (int u = 0; u < NSET; ++u)
+  for (int g = 0; g < QW; ++g) {
+    const int64_t ql = (tile * QW + g) * 32 + r;
+    if (ql < n_q) {
+      // slot order inside a query's G values does not matter to the consumer
+      f32x4 *dst = reinterpret_cast<f32x4 *>(out_min + ((ql * S + split) * NSET * 32 + h * 16));
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        f32x4 v;
+      for (int u = 0; u < NSET; ++u)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = mn[u][4 * j + i] * inv_s2;   // exact: s² is a power of two
-        dst[u * 8 + j] = v;
-      }
+        for (int j = 0; j < 4; ++j) {
+          f32x4 v;
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = mn[g][u][4 * j + i] * inv_s2;   // exact: s² is a power of two
+          dst[u * 8 + j] = v;
+        }
+    }
   }
 }
 
@@ -1027,14 +1040,10 @@ __device__ __forceinline__ void wavebufc_flush(WaveBufC &wb, const float *__rest
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src),   \
                                    (void __attribute__((address_space(3))) *)(dst), 16, 0, 0)
 
-// the passing pairs of one 32 x 32 tile (acc = coarse distance − threshold: sign bit set = pass) into the wave's
-// parking buffer; g = the wave's query group the tile belongs to
-__device__ __forceinline__ void collect16c_tile(f32x16 &acc, int64_t b, int64_t NB, int64_t self_blk, unsigned self_bit,
-                                                unsigned tail_vm, int min_first, int g, WaveBufC &wb,
-                                                const float *__restrict__ x, int d, int vec, int64_t q_begin,
-                                                const float *__restrict__ T, u64 *__restrict__ buf,
-                                                int *__restrict__ cursor, int64_t q0, int64_t n_q, int cap, int lane) {
-  const int r = lane & 31, h = lane >> 5;
+// the passing pairs of one 32 x 32 tile (acc = coarse distance − threshold: sign bit set = pass) as a lane mask:
+// bit (15 − e) = pair (this lane's query, candidate entry e) passes; 0 for the whole wave when the tile is rejected
+__device__ __forceinline__ unsigned collect16c_mask(f32x16 &acc, int64_t b, int64_t NB, int64_t self_blk, unsigned self_bit,
+                                                    unsigned tail_vm, int min_first) {
   if (__any(b == self_blk) || b == NB - 1) {
     // masked pairs (the query itself, padding rows of the last block) become +0; plain bit arithmetic on a per-lane
     // mask, so that no per-entry lane masks live in scalar registers across the loop
@@ -1053,24 +1062,36 @@ __device__ __forceinline__ void collect16c_tile(f32x16 &acc, int64_t b, int64_t 
     o |= __float_as_uint(acc[11]) | __float_as_uint(acc[12]);
     o |= __float_as_uint(acc[13]) | __float_as_uint(acc[14]);
     o |= __float_as_uint(acc[15]);
-    if (!__any((int)o < 0)) return;
+    if (!__any((int)o < 0)) return 0u;
   }
-  // hm bit (15 − e) = sign of acc[e]
   unsigned hm = 0;
 #pragma unroll
   for (int e = 0; e < 16; ++e) hm = __builtin_amdgcn_alignbit(hm, __float_as_uint(acc[e]), 31);
-  const unsigned cbase = (unsigned)(b * 32) + 4 * h;
-  while (true) {   // one parked pair per lane and round; wave-uniform trip count
-    const unsigned long long lm = __ballot(hm != 0);
+  return hm;
+}
+
+// parks the pairs of up to four tiles at once: m64 holds their lane masks, 16 bits per tile slot, slot = (block − b0)·QW
+// + query group.  One pair per lane and round, wave-uniform trip count (the rounds cost a ballot, a popcount and a
+// branch each: sharing them between the tiles of two blocks is what this grouping is for).
+template <int QW>
+__device__ __forceinline__ void collect16c_park(unsigned long long m64, int64_t b0, WaveBufC &wb,
+                                                const float *__restrict__ x, int d, int vec, int64_t q_begin,
+                                                const float *__restrict__ T, u64 *__restrict__ buf,
+                                                int *__restrict__ cursor, int64_t q0, int64_t n_q, int cap, int lane) {
+  const int r = lane & 31, h = lane >> 5;
+  const unsigned cbase = (unsigned)(b0 * 32) + 4 * h;
+  while (true) {
+    const unsigned long long lm = __ballot(m64 != 0);
     if (!lm) break;
     const int cnt = __builtin_popcountll(lm);
     if (wb.n + cnt > COL_WB) wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
-    if (hm != 0) {
-      const int e = 15 - (__builtin_ffs((int)hm) - 1);
+    if (m64 != 0) {
+      const int bit = __builtin_ffsll((long long)m64) - 1;
+      const int slot = bit >> 4, e = 15 - (bit & 15);
       const int pos = wb.n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(lm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)lm, 0u));
-      wb.cand[pos] = cbase + (e & 3) + 8 * (e >> 2);
-      wb.qr[pos] = g * 32 + r;
-      hm &= hm - 1;
+      wb.cand[pos] = cbase + 32 * (slot / QW) + (e & 3) + 8 * (e >> 2);
+      wb.qr[pos] = (slot % QW) * 32 + r;
+      m64 &= m64 - 1;
     }
     wb.n += cnt;
   }
@@ -1195,6 +1216,7 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int t = 0; t <= ND; ++t) ah[cb][t] = sbuf[cb * HU + t * 64];
+    unsigned long long m64 = 0;
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb) {
       const int64_t b = b_lo + st * CB + cb;
@@ -1210,8 +1232,12 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
         }
 #pragma unroll
         for (int g = 0; g < QW; ++g)
-          collect16c_tile(acc[g], b, NB, self_blk[g], self_bit[g], tail_vm, min_first, g, wb, x, d, vec, q_begin, T, buf,
-                          cursor, q0, n_q, cap, lane);
+          m64 |= (unsigned long long)collect16c_mask(acc[g], b, NB, self_blk[g], self_bit[g], tail_vm, min_first)
+                 << (16 * ((cb & 1) * QW + g));
+      }
+      if ((cb & 1) || cb == CB - 1) {   // the tiles of two candidate blocks are parked together
+        collect16c_park<QW>(m64, b - (cb & 1), wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
+        m64 = 0;
       }
     }
     // the next stage's data must have landed (in the tail fewer stages are in flight than the count assumes)
@@ -1644,6 +1670,7 @@ struct KnnWorkspace {
   int collect_splits = 0;                  // 0 = chosen per call; > 0 = forced (tools/knn_split_sweep.sh)
   int sample_splits = 0;                   // same for the candidate ranges of the fp16 sample pass
   int sample_stride = 0;                   // 0 = CC_KNN_SAMPLE; > 0 = every n-th candidate block is sampled
+  int sample_qw = 0;                       // 0 = chosen per call; 1 / 2 = query groups per wave of the fp16 sample pass
   int64_t last_fallback = 0;
   int64_t last_full_scan = 0;              // fallback queries that had to scan every candidate in float64 VALU
   void release() {
@@ -1690,27 +1717,23 @@ static int run_select(int NG, const SelectArgs &a, int KP, int CAP, int S, int64
   return CC_OK;
 }
 
-static int run_sample16(int ND, int NSET, const h8 *P16, const SelectArgs &a, float s, int S, int64_t NBs, int bstride,
-                        float *out_min) {
-  const int64_t nwaves = ceil_div(a.n_q, 32) * S;
-#define CC_SMP16(NDV, NS)                                                                                         \
-  hipLaunchKernelGGL((knn_sample16_kernel<NDV, NS>), dim3((unsigned)nwaves), dim3(64), 0, stream(), P16, a.norms, a.x, \
-                     a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, s, S, NBs, bstride, out_min)
-  if (NSET == 2) {
-    switch (ND) {
-      case 1: CC_SMP16(1, 2); break;
-      case 2: CC_SMP16(2, 2); break;
-      case 4: CC_SMP16(4, 2); break;
-      default: CC_REQUIRE(false, "knn: no fp16 sample kernel for ND=%d", ND);
-    }
-  } else {
-    switch (ND) {
-      case 1: CC_SMP16(1, 4); break;
-      case 2: CC_SMP16(2, 4); break;
-      case 4: CC_SMP16(4, 4); break;
-      default: CC_REQUIRE(false, "knn: no fp16 sample kernel for ND=%d", ND);
-    }
+static int run_sample16(int ND, int NSET, int QW, const h8 *P16, const SelectArgs &a, float s, int S, int64_t NBs,
+                        int bstride, float *out_min) {
+  const int64_t nwaves = ceil_div(a.n_q, 32 * QW) * S;
+#define CC_SMP16(NDV, NS, QWV)                                                                                    \
+  hipLaunchKernelGGL((knn_sample16_kernel<NDV, NS, QWV>), dim3((unsigned)nwaves), dim3(64), 0, stream(), P16, a.norms, \
+                     a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, s, S, NBs, bstride, out_min)
+#define CC_SMP16_ND(NS, QWV)                                                                                      \
+  switch (ND) {                                                                                                   \
+    case 1: CC_SMP16(1, NS, QWV); break;                                                                          \
+    case 2: CC_SMP16(2, NS, QWV); break;                                                                          \
+    case 4: CC_SMP16(4, NS, QWV); break;                                                                          \
+    default: CC_REQUIRE(false, "knn: no fp16 sample kernel for ND=%d", ND);                                       \
   }
+  if (NSET == 2 && QW == 2) { CC_SMP16_ND(2, 2) }
+  else if (NSET == 2) { CC_SMP16_ND(2, 1) }
+  else { CC_SMP16_ND(4, 1) }
+#undef CC_SMP16_ND
 #undef CC_SMP16
   CC_HIP(hipGetLastError());
   return CC_OK;
@@ -1949,6 +1972,10 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
         // range is split so that the per-SIMD wave count rounds up by little (3125 whole-range waves would put 4 on
         // some SIMDs and 3 on the rest), at a fixed cost per wave of ~8 tiles.
         const int NSET = m <= 20 ? 2 : 4;
+        // 64 queries per wave (two groups sharing each candidate fragment: half the L2 -> register traffic per MFMA;
+        // one rank of configs[3] 7.4 -> 5.9 ms) unless the query range is short
+        const int QWS = (NSET == 2 && ws.sample_qw != 1 && (ws.sample_qw == 2 || n_q >= 32768)) ? 2 : 1;
+        const int64_t stiles = ceil_div(n_q, 32 * QWS);
         int SS = 1;
         int64_t NBss = NB;
         {
@@ -1958,7 +1985,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
           } else {
             double best = 1e300;
             for (int cand = 1; cand <= 8; ++cand) {
-              const double cost = (double)ceil_div(tiles * cand, 1024) * ((double)ceil_div(NB, (int64_t)cand * SAMPLE) + 8.0);
+              const double cost = (double)ceil_div(stiles * cand, 1024) * ((double)ceil_div(NB, (int64_t)cand * SAMPLE) + 8.0);
               if (cost < best * 0.97) { best = cost; want = cand; }
             }
           }
@@ -1968,7 +1995,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
         }
         const int nslots = 32 * NSET * SS;
         if ((rc = smin.alloc(sizeof(float) * (size_t)n_q * (size_t)nslots))) return rc;
-        if ((rc = run_sample16(ND16, NSET, P16.as<h8>(), sa, scale16, SS, NBss, SAMPLE, smin.as<float>()))) return rc;
+        if ((rc = run_sample16(ND16, NSET, QWS, P16.as<h8>(), sa, scale16, SS, NBss, SAMPLE, smin.as<float>()))) return rc;
         hipLaunchKernelGGL(knn_slot_threshold_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), 0, stream(),
                            smin.as<float>(), n_q, nslots, m, Tq.as<float>());
       } else {
@@ -2207,6 +2234,10 @@ int cc_knn_set_option(void *knn, int option, int value) {
     case CC_KNN_OPT_SAMPLE_SPLITS:
       CC_REQUIRE(value >= 0 && value <= 16, "sample splits %d outside [0, 16]", value);
       ws->sample_splits = value;
+      break;
+    case CC_KNN_OPT_SAMPLE_GROUPS:
+      CC_REQUIRE(value >= 0 && value <= 2, "sample groups %d outside [0, 2]", value);
+      ws->sample_qw = value;
       break;
     case CC_KNN_OPT_SAMPLE_STRIDE:
       CC_REQUIRE(value >= 0 && value <= 64, "sample stride %d outside [0, 64]", value);

@@ -75,11 +75,13 @@ def use_fp16_sample(on):
     _lib.check(_lib.lib().cc_knn_set_option(None, 3, 1 if on else 0))
 
 
-def set_sample_layout(splits=0, stride=0):
-    """Tuning / test hook: candidate ranges of the fp16 sample pass and the sampling stride in candidate blocks
-    (0 = chosen by the library).  Results never depend on them (CC_KNN_OPT_SAMPLE_SPLITS / _STRIDE)."""
+def set_sample_layout(splits=0, stride=0, groups=0):
+    """Tuning / test hook: candidate ranges of the fp16 sample pass, the sampling stride in candidate blocks and the
+    32-query groups per wave (0 = chosen by the library).  Results never depend on them
+    (CC_KNN_OPT_SAMPLE_SPLITS / _STRIDE / _GROUPS)."""
     _lib.check(_lib.lib().cc_knn_set_option(None, 7, int(splits)))
     _lib.check(_lib.lib().cc_knn_set_option(None, 8, int(stride)))
+    _lib.check(_lib.lib().cc_knn_set_option(None, 9, int(groups)))
 
 
 def use_fp64_prefilter(on):

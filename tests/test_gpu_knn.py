@@ -187,6 +187,11 @@ def test_sample_layouts_never_change_the_result(hip, oracle_built, n, d, k):
             idx, dist = cc.knn_graph(x, k)
             assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (splits, stride)
         hipknn.set_sample_layout(0, 0)
+        for groups in (1, 2):                                # 32 or 64 queries per wave of the sample pass
+            hipknn.set_sample_layout(0, 0, groups)
+            idx, dist = cc.knn_graph(x, k)
+            assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), groups
+        hipknn.set_sample_layout(0, 0)
         idx0, _ = cc.knn_graph(x, k)
         fb_slots = hipknn.last_fallback_count()
         hipknn.use_fp16_sample(False)
