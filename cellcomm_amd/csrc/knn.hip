@@ -679,22 +679,48 @@ __global__ void knn_pack16_kernel(const float *__restrict__ x, const float *__re
   P16[f] = panel16_unit(x, mu, norms, cand, cand < N, d, ND, t, lane >> 5, s, s * s * (1.0f / 256.0f), false);
 }
 
+// direct fp32 evaluation of one squared distance from the original coordinates (error ~d·2^-24 of the distance itself)
+__device__ __forceinline__ float fine_dist(const float *__restrict__ xq, const float *__restrict__ xc, int d, int vec) {
+  float sum = 0.f;
+  if (vec) {
+    for (int t = 0; t < d; t += 4) {
+      const float4 a = *reinterpret_cast<const float4 *>(xq + t), b = *reinterpret_cast<const float4 *>(xc + t);
+      float df = a.x - b.x; sum = fmaf(df, df, sum);
+      df = a.y - b.y; sum = fmaf(df, df, sum);
+      df = a.z - b.z; sum = fmaf(df, df, sum);
+      df = a.w - b.w; sum = fmaf(df, df, sum);
+    }
+  } else {
+    for (int t = 0; t < d; ++t) {
+      const float df = xq[t] - xc[t];
+      sum = fmaf(df, df, sum);
+    }
+  }
+  return sum;
+}
+
 // ---- sample pass on the fp16 matrix cores: slot minima instead of lists -------------------------
 // The sample only has to produce a threshold T[q] under which at least m candidates lie.  A 32 x 32 tile leaves
 // each lane with 16 distances of ITS query to 16 candidates; the lane keeps the running minimum of every such
 // register slot over the sampled tiles, NSET interleaved sets of them (tile j feeds set j % NSET).  A query thus
-// ends with G = 32·NSET minima (x the candidate ranges the pass is split over), each the distance of a DIFFERENT
-// candidate, and T = the m-th smallest of them (knn_slot_threshold_kernel) has >= m candidates at or below it.
-// It is a little looser than the m-th best of the whole sample (two of the best m may share a slot: the expected
-// rank is G·ln(G/(G-m)), 18.4 instead of 16 at G = 64) but costs one v_min per distance instead of an LDS list
-// insertion, needs no LDS, and leaves the pass bound by its MFMAs and fragment loads.  Arithmetic: the 3·ND + 1
-// products of the fp16 split (hi·hi + hi·lo + lo·hi), scaled by s² (a power of two) and unscaled exactly on the
-// way out.
+// ends with G = 32·NSET minima (x the candidate ranges the pass is split over), each belonging to a DIFFERENT
+// candidate.  The tile is the coarse one of the collect (hi·hi product + norm step: ND + 1 MFMAs), made positive by
+// adding the coarse bound through the query's norm slot, and the low SKEY_BITS of each value are replaced by the
+// index of the sampled tile, so that one v_and_or + one v_min_u32 per distance keep the minimum AND where it came
+// from.  knn_slot_threshold_kernel then takes the m smallest keys of a query, re-evaluates those m candidates
+// directly in fp32 (the arithmetic of the collect's final test) and returns the largest of the m distances: m
+// distinct candidates lie at or below T whatever the coarse values were worth.  T is a little looser than the m-th
+// best of the whole sample (two of the best m may share a slot: the expected rank is G·ln(G/(G-m)), 18.4 instead of
+// 16 at G = 64) but the pass costs 5 MFMAs + 32 vector instructions per tile where round 1's list select cost
+// 13 + 511, needs no LDS, and is cheap enough to sample every 4th block instead of every 8th.
+constexpr int SKEY_BITS = 13;                       // sampled tiles per candidate range <= 8192
+constexpr unsigned SKEY_MASK = (1u << SKEY_BITS) - 1u;
+
 template <int ND, int NSET, int QW>
 __global__ __launch_bounds__(64) void knn_sample16_kernel(
-    const h8 *__restrict__ P16, const float *__restrict__ norms, const float *__restrict__ x,
-    const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
-    float s, int S, int64_t NBs, int bstride, float *__restrict__ out_min) {
+    const h8 *__restrict__ P16, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
+    const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin,
+    int64_t n_q, int include_self, float s, int S, int64_t NBs, int bstride, unsigned *__restrict__ out_key) {
   constexpr int NT = 2 * ND + 1;
   const int64_t tile = blockIdx.x / S;
   const int split = blockIdx.x % S;
@@ -702,10 +728,10 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
   const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
   const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
-  const float s2 = s * s, inv_s2 = 1.0f / s2;
+  const float s2 = s * s;
 
   // QW query groups of 32 share every candidate fragment (half the fragment traffic per MFMA when QW = 2)
-  h8 bqh[QW][ND + 1], bql[QW][ND];
+  h8 bqh[QW][ND + 1];
   int64_t self_blk[QW];
   unsigned self_bit[QW];
 #pragma unroll
@@ -714,15 +740,21 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
     const bool qvalid = ql < n_q;
     const int64_t q = q_begin + ql;
 #pragma unroll
-    for (int t = 0; t <= ND; ++t)
+    for (int t = 0; t < ND; ++t)
       bqh[g][t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
 #pragma unroll
-    for (int t = 0; t < ND; ++t) bql[g][t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, ND + 1 + t, h, -2.0f * s, 0.f, true);
+    for (int j = 0; j < 8; ++j) bqh[g][ND][j] = (_Float16)0.f;
+    if (qvalid) {
+      // norm slot = s²‖q−μ‖² + the bound of the coarse tile (see knn_collect16c_kernel): every value is positive
+      const float nq = norms[q];
+      const float bias = 1.953125e-3f * (nq + __uint_as_float(maxnorm_bits[0])) * s2 + (float)d * 3.0517578125e-5f;
+      bqh[g][ND] = query_norm_unit((nq * s2 + bias) * (1.0f / 256.0f), h);
+    }
     self_blk[g] = -1;
     self_bit[g] = 0;
-    if (qvalid && !include_self) {
+    if (!include_self) {   // (rows of invalid queries are masked like a self pair: their keys are never read)
       const int row = (int)(q & 31);
-      if (((row >> 2) & 1) == h) {
+      if (qvalid && ((row >> 2) & 1) == h) {
         self_blk[g] = q >> 5;
         self_bit[g] = 1u << ((row & 3) | ((row >> 3) << 2));
       }
@@ -733,23 +765,24 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
   for (int e = 0; e < 16; ++e)
     if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
 
-  f32x16 mn[QW][NSET];
+  using u32x16 = __attribute__((ext_vector_type(16))) unsigned;
+  u32x16 mn[QW][NSET];
 #pragma unroll
   for (int g = 0; g < QW; ++g)
 #pragma unroll
     for (int u = 0; u < NSET; ++u)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mn[g][u][e] = INFINITY;
+      for (int e = 0; e < 16; ++e) mn[g][u][e] = 0xffffffffu;
+  const unsigned keep = ~SKEY_MASK;   // in a register: v_and_or takes one scalar operand, the tile index
 
   // two register sets of candidate operands, ping-pong: the next sampled block loads while this one computes
-  h8 ah[2][ND + 1], al[2][ND];
+  h8 ah[2][ND + 1];
   {
     const h8 *pb = P16 + b_lo * (NT * 64) + lane;
 #pragma unroll
     for (int t = 0; t <= ND; ++t) ah[0][t] = pb[t * 64];
-#pragma unroll
-    for (int t = 0; t < ND; ++t) al[0][t] = pb[(ND + 1 + t) * 64];
   }
+  unsigned j = 0;   // index of the sampled tile inside this range
   for (int64_t b0 = b_lo; b0 < b_hi; b0 += (int64_t)NSET * bstride) {
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
@@ -761,28 +794,29 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
           const h8 *pb = P16 + ((bn < b_hi) ? bn : b) * (NT * 64) + lane;
 #pragma unroll
           for (int t = 0; t <= ND; ++t) ah[nxt][t] = pb[t * 64];
+        }
+        f32x16 acc[QW];
 #pragma unroll
-          for (int t = 0; t < ND; ++t) al[nxt][t] = pb[(ND + 1 + t) * 64];
+        for (int g = 0; g < QW; ++g) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+#pragma unroll
+          for (int t = 0; t <= ND; ++t) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bqh[g][t], acc[g], 0, 0, 0);
         }
 #pragma unroll
         for (int g = 0; g < QW; ++g) {
-          f32x16 acc;
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-#pragma unroll
-          for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bqh[g][t], acc, 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bql[g][t], acc, 0, 0, 0);
-#pragma unroll
-          for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[cur][t], bqh[g][t], acc, 0, 0, 0);
           if (__any(b == self_blk[g]) || b == NB - 1) {
             const unsigned km = (b == self_blk[g] ? self_bit[g] : 0u) | (b == NB - 1 ? ~tail_vm & 0xffffu : 0u);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[e] = ((km >> e) & 1u) ? INFINITY : acc[e];
+            for (int e = 0; e < 16; ++e) acc[g][e] = ((km >> e) & 1u) ? INFINITY : acc[g][e];
           }
 #pragma unroll
-          for (int e = 0; e < 16; ++e) asm("v_min_f32 %0, %1, %2" : "=v"(mn[g][u][e]) : "v"(mn[g][u][e]), "v"(acc[e]));
+          for (int e = 0; e < 16; ++e) {
+            const unsigned key = (__float_as_uint(acc[g][e]) & keep) | j;
+            mn[g][u][e] = key < mn[g][u][e] ? key : mn[g][u][e];
+          }
         }
+        ++j;
       }
     }
   }
@@ -790,26 +824,29 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
   for (int g = 0; g < QW; ++g) {
     const int64_t ql = (tile * QW + g) * 32 + r;
     if (ql < n_q) {
-      // slot order inside a query's G values does not matter to the consumer
-      f32x4 *dst = reinterpret_cast<f32x4 *>(out_min + ((ql * S + split) * NSET * 32 + h * 16));
+      // slot s = u·32 + h·16 + e of (query, range): the consumer decodes the candidate from s and the key's tile index
+      using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+      u32x4 *dst = reinterpret_cast<u32x4 *>(out_key + ((ql * S + split) * NSET * 32 + h * 16));
 #pragma unroll
       for (int u = 0; u < NSET; ++u)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          f32x4 v;
+        for (int jj = 0; jj < 4; ++jj) {
+          u32x4 v;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = mn[g][u][4 * j + i] * inv_s2;   // exact: s² is a power of two
-          dst[u * 8 + j] = v;
+          for (int i = 0; i < 4; ++i) v[i] = mn[g][u][4 * jj + i];
+          dst[u * 8 + jj] = v;
         }
     }
   }
 }
 
-// T[q] = the m-th smallest of the query's n slot minima (n = 32·NSET·S, a multiple of 64; +inf when fewer than m
-// are finite).  One wave per query: bisection over the bits of the order-preserving integer image of the floats,
-// counting with ballots.
-__global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const float *__restrict__ smin, int64_t n_q, int n,
-                                                                 int m, float *__restrict__ T) {
+// T[q] from the query's n = 32·NSET·S slot keys (a multiple of 64; layout and key format: knn_sample16_kernel).  One
+// wave per query: the m-th smallest key by bisection over its bits, counting with ballots; the lanes holding keys at or
+// below it (m of them, more on ties) evaluate their candidate's distance directly in fp32, T = the largest of those.
+// Fewer than m real keys: T = +inf (the collect lists everything it can hold; stage 3 takes over if that overflows).
+__global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const unsigned *__restrict__ skey, const float *__restrict__ x,
+                                                                 int d, int64_t q_begin, int64_t n_q, int n, int m, int NSET,
+                                                                 int64_t NBs, int bstride, float *__restrict__ T) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t ql = (int64_t)blockIdx.x * 4 + wave;
   if (ql >= n_q) return;
@@ -817,7 +854,7 @@ __global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const float *__
   unsigned key[MAXR];
   const int nreg = n / 64;
 #pragma unroll
-  for (int j = 0; j < MAXR; ++j) key[j] = j < nreg ? f32_to_ordered(smin[ql * n + j * 64 + lane]) : 0xffffffffu;
+  for (int j = 0; j < MAXR; ++j) key[j] = j < nreg ? skey[ql * n + j * 64 + lane] : 0xffffffffu;
   unsigned prefix = 0;
   for (int bit = 31; bit >= 0; --bit) {
     const unsigned trial = prefix | ((1u << bit) - 1u);
@@ -827,8 +864,28 @@ __global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const float *__
       if (j < nreg) c += __builtin_popcountll(__ballot(key[j] <= trial));
     if (c < m) prefix |= 1u << bit;
   }
-  const unsigned inf_key = f32_to_ordered(INFINITY);
-  if (lane == 0) T[ql] = prefix >= inf_key ? INFINITY : ordered_to_f32(prefix);
+  float worst = 0.f;
+  if (prefix < 0x7f800000u) {   // the m-th smallest key is a real distance
+    const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
+    const float *xq = x + (q_begin + ql) * d;
+    const int per_range = NSET * 32;
+#pragma unroll
+    for (int j = 0; j < MAXR; ++j) {
+      if (j < nreg && key[j] <= prefix) {
+        const int slot = j * 64 + lane;
+        const int split = slot / per_range, sl = slot - split * per_range;
+        const int e = sl & 15, h = (sl >> 4) & 1;
+        const int64_t b = split * NBs + (int64_t)(key[j] & SKEY_MASK) * bstride;
+        const int64_t cand = b * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        worst = fmaxf(worst, fine_dist(xq, x + cand * d, d, vec));
+      }
+    }
+  } else {
+    worst = INFINITY;
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) worst = fmaxf(worst, __shfl_xor(worst, o));
+  if (lane == 0) T[ql] = worst;
 }
 
 template <int ND>
@@ -998,25 +1055,6 @@ struct WaveBufC {
   int *qr;          // [COL_WB] query column 0..31
   int n;
 };
-
-__device__ __forceinline__ float fine_dist(const float *__restrict__ xq, const float *__restrict__ xc, int d, int vec) {
-  float sum = 0.f;
-  if (vec) {
-    for (int t = 0; t < d; t += 4) {
-      const float4 a = *reinterpret_cast<const float4 *>(xq + t), b = *reinterpret_cast<const float4 *>(xc + t);
-      float df = a.x - b.x; sum = fmaf(df, df, sum);
-      df = a.y - b.y; sum = fmaf(df, df, sum);
-      df = a.z - b.z; sum = fmaf(df, df, sum);
-      df = a.w - b.w; sum = fmaf(df, df, sum);
-    }
-  } else {
-    for (int t = 0; t < d; ++t) {
-      const float df = xq[t] - xc[t];
-      sum = fmaf(df, df, sum);
-    }
-  }
-  return sum;
-}
 
 __device__ __forceinline__ void wavebufc_flush(WaveBufC &wb, const float *__restrict__ x, int d, int vec, int64_t q_begin,
                                                const float *__restrict__ T, u64 *__restrict__ buf,
@@ -1717,12 +1755,12 @@ static int run_select(int NG, const SelectArgs &a, int KP, int CAP, int S, int64
   return CC_OK;
 }
 
-static int run_sample16(int ND, int NSET, int QW, const h8 *P16, const SelectArgs &a, float s, int S, int64_t NBs,
-                        int bstride, float *out_min) {
+static int run_sample16(int ND, int NSET, int QW, const h8 *P16, const SelectArgs &a, const unsigned *maxnorm_bits, float s,
+                        int S, int64_t NBs, int bstride, unsigned *out_key) {
   const int64_t nwaves = ceil_div(a.n_q, 32 * QW) * S;
 #define CC_SMP16(NDV, NS, QWV)                                                                                    \
   hipLaunchKernelGGL((knn_sample16_kernel<NDV, NS, QWV>), dim3((unsigned)nwaves), dim3(64), 0, stream(), P16, a.norms, \
-                     a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, s, S, NBs, bstride, out_min)
+                     maxnorm_bits, a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, s, S, NBs, bstride, out_key)
 #define CC_SMP16_ND(NS, QWV)                                                                                      \
   switch (ND) {                                                                                                   \
     case 1: CC_SMP16(1, NS, QWV); break;                                                                          \
@@ -1854,17 +1892,30 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
 
   // Route 1b (sampled threshold + collect) is the product route; route 1a (full select with a running
   // threshold) remains for inputs below 8 sampled blocks that do not fit the collect buffer (none with
-  // the default knobs) and as the cross-check behind cc_knn_force_full_select.  Sample = every 8th candidate block, T = the
-  // m-th best of the sample (m = max(16, 3k/8)): the number of candidates below T is ~Gamma(m)·8, i.e.
-  // 8m >= 3k on average, >= k and <= 4·8m except with probability < 1e-4 per query; either miss only
-  // sends that query to the float64 fallback.
+  // the default knobs) and as the cross-check behind cc_knn_force_full_select.  Sample = every S-th candidate block
+  // (S = 3..8, below), T = (about) the m-th best of the sample, m = max(16, 3k/S): the number of candidates below T
+  // is ~Gamma(m)·S, i.e. S·m >= 3k on average, >= k and <= 4·S·m except with probability < 1e-4 per query; either
+  // miss only sends that query to the float64 fallback.
 #ifndef CC_KNN_SAMPLE
 #define CC_KNN_SAMPLE 8
 #endif
-  const int SAMPLE = ws.sample_stride > 0 ? ws.sample_stride : CC_KNN_SAMPLE;
 #ifndef CC_KNN_MIN_M
 #define CC_KNN_MIN_M 16   // m >= k for k <= 16, so the sampled points alone fill the list
 #endif
+  // Sampling stride.  The sample costs ~N/stride tiles per query, the collect parks ~1.15·stride·m pairs per query:
+  // the sum is smallest near stride ∝ sqrt(N/m) (measured with the slot-minima sample, CC_KNN_OPT_SAMPLE_STRIDE
+  // sweeps: 100k candidates, k = 15: 4.13 / 3.64 / 3.43 / 3.36 / 4.67 ms at stride 8 / 6 / 4 / 3 / 2; 1M: 24.1 / 24.5 /
+  // 25.7 / 27.7 / 35.2; 500k, k = 50: 8.2 / 8.0 / 8.9 / 9.4 / 11.1).  The list-based fp32 sample keeps every 8th block.
+  int SAMPLE = CC_KNN_SAMPLE;
+  if (ws.sample_stride > 0) {
+    SAMPLE = ws.sample_stride;
+  } else if (ws.use_fp16_select && ws.use_fp16_collect && d <= 64) {
+    const int m8 = std::max(CC_KNN_MIN_M, (3 * k + 7) / 8);
+    const long st = lround(sqrt((double)N / (double)m8) / 22.6);
+    // ... but m = 3k / stride has to stay well below the 128 slots a query has per candidate range (m = 100 of 128
+    // would put the threshold at rank 195: k = 100 at 100k candidates 7.4 ms with stride 8, 8.4 with 3)
+    SAMPLE = (int)std::min(8L, std::max(std::max(3L, st), (long)ceil_div(3 * k, 40)));
+  }
   const int m_min = CC_KNN_MIN_M, m_k = (3 * k + SAMPLE - 1) / SAMPLE;   // SAMPLE·m >= 3k expected below T
   const int m = m_k > m_min ? m_k : m_min;
   // Route 1a pays ~50 us per block while its lists fill (every block overflows them), 1-4 ms even at
@@ -1966,14 +2017,15 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
       if (collect_all) {
         hipLaunchKernelGGL(knn_fill_kernel, dim3((unsigned)ceil_div(n_q, 256)), dim3(256), 0, stream(), Tq.as<float>(),
                            n_q, INFINITY);
-      } else if (scale16 > 0.f && ws.use_fp16_select && ND16 <= 4) {   // ND = 8 (d > 64): fp32 lists below
-        // slot minima (knn_sample16_kernel): T = the m-th smallest of 32·NSET·SS minima per query.  One wave per
-        // 32 queries and candidate range; what counts is how evenly the waves load the 1024 SIMDs: the candidate
-        // range is split so that the per-SIMD wave count rounds up by little (3125 whole-range waves would put 4 on
-        // some SIMDs and 3 on the rest), at a fixed cost per wave of ~8 tiles.
+      } else if (scale16 > 0.f && ws.use_fp16_select && ND16 <= 4 &&   // ND = 8 (d > 64): fp32 lists below
+                 ceil_div(ceil_div(NB, SAMPLE), (int64_t)(32 / (m <= 20 ? 2 : 4))) <= (int64_t)(SKEY_MASK + 1)) {
+        // slot minima (knn_sample16_kernel + knn_slot_threshold_kernel).  One wave per 32 or 64 queries and candidate
+        // range; what counts is how evenly the waves load the 1024 SIMDs: the candidate range is split so that the
+        // per-SIMD wave count rounds up by little (3125 whole-range waves would put 4 on some SIMDs and 3 on the
+        // rest), at a fixed cost per wave of ~8 tiles; a range holds at most 2^SKEY_BITS sampled tiles.
         const int NSET = m <= 20 ? 2 : 4;
-        // 64 queries per wave (two groups sharing each candidate fragment: half the L2 -> register traffic per MFMA;
-        // one rank of configs[3] 7.4 -> 5.9 ms) unless the query range is short
+        // 64 queries per wave (two groups sharing each candidate fragment: half the L2 -> register traffic per MFMA)
+        // unless the query range is short
         const int QWS = (NSET == 2 && ws.sample_qw != 1 && (ws.sample_qw == 2 || n_q >= 32768)) ? 2 : 1;
         const int64_t stiles = ceil_div(n_q, 32 * QWS);
         int SS = 1;
@@ -1989,15 +2041,21 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
               if (cost < best * 0.97) { best = cost; want = cand; }
             }
           }
+          const int need = (int)ceil_div(ceil_div(NB, SAMPLE), (int64_t)(SKEY_MASK + 1));
+          if (want < need) want = need;
           if (want * NSET > 32) want = 32 / NSET;
           make_splits(NB, want, &SS, &NBss);
           if (SS == 1) NBss = NB;
+          CC_REQUIRE(ceil_div(NBss, SAMPLE) <= (int64_t)(SKEY_MASK + 1), "knn: %lld sampled tiles per range",
+                     (long long)ceil_div(NBss, SAMPLE));
         }
         const int nslots = 32 * NSET * SS;
-        if ((rc = smin.alloc(sizeof(float) * (size_t)n_q * (size_t)nslots))) return rc;
-        if ((rc = run_sample16(ND16, NSET, QWS, P16.as<h8>(), sa, scale16, SS, NBss, SAMPLE, smin.as<float>()))) return rc;
+        if ((rc = smin.alloc(sizeof(unsigned) * (size_t)n_q * (size_t)nslots))) return rc;
+        if ((rc = run_sample16(ND16, NSET, QWS, P16.as<h8>(), sa, maxn.as<unsigned>(), scale16, SS, NBss, SAMPLE,
+                               smin.as<unsigned>())))
+          return rc;
         hipLaunchKernelGGL(knn_slot_threshold_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), 0, stream(),
-                           smin.as<float>(), n_q, nslots, m, Tq.as<float>());
+                           smin.as<unsigned>(), d_x, d, q_begin, n_q, nslots, m, NSET, NBss, SAMPLE, Tq.as<float>());
       } else {
         // fp32 route: select with m-entry LDS lists over the sampled blocks, T = the m-th best of the sample
 #ifndef CC_KNN_SAMPLE_SPARE
