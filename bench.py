@@ -18,6 +18,7 @@ JSON line and exits with the child's status.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -371,20 +372,22 @@ def main():
         knn_ms = sum(v['ms'] for v in ksel) / args.steps
         if knn_ms > 0:
             # algorithmic work of the search: 2 * queries * candidates * d.  Executed on the fp16 matrix
-            # cores: the collect pass = ONE fp16 product per pair (hi x hi) + the norm step, ND + 1 MFMA K-steps of 16
-            # over all candidates; the sample pass = the three-product form, 3 ND + 1 K-steps, over every 8th block
+            # cores: ONE fp16 product per pair (hi x hi) + the norm step = ND + 1 MFMA K-steps of 16, by the collect
+            # pass over all candidates and by the sample pass over every S-th block (S as csrc/knn.hip chooses it)
             knn_flop = 2.0 * (hi - lo) * args.cells * args.latent
             ktf = knn_flop / (knn_ms * 1e-3) / 1e12
             nd = -(-args.latent // 16)
-            executed = 16.0 * ((nd + 1) + (3 * nd + 1) / 8.0) / args.latent
+            m8 = max(16, -(-3 * args.k // 8))
+            stride = min(8, max(3, int(math.floor((args.cells / m8) ** 0.5 / 22.6 + 0.5)), -(-3 * args.k // 40)))
+            executed = 16.0 * (nd + 1) * (1.0 + 1.0 / stride) / args.latent
             line['roofline_knn'] = {'kernel': 'knn_sample16 + knn_collect16c + knn_merge + knn_rerank (per step)',
                                     'bound': 'mfma', 'achieved': ktf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': ktf / PEAK_F16_MFMA_TFLOPS, 'executed_fp16_tflops': executed * ktf,
                                     'ms_per_step': knn_ms, 'flop_per_step': knn_flop, 'traffic': None,
-                                    'note': 'achieved = algorithmic 2*q*c*d FLOP / stage time; executed = x%.3f (collect: '
-                                            'one fp16 product + norm step over all candidates, sample: three-product form '
-                                            'over 1/8 of them); parking and re-checking the passing pairs (VALU/LDS) shares '
-                                            'the time' % executed}
+                                    'note': 'achieved = algorithmic 2*q*c*d FLOP / stage time; executed = x%.3f (one fp16 '
+                                            'product + norm step per pair: collect over all candidates, sample over every '
+                                            '%d-th block); parking and re-checking the passing pairs (VALU/LDS) shares '
+                                            'the time' % (executed, stride)}
         gather = prof['gather']
         if gather['ms'] > 0:
             gbs = gather['work'] / (gather['ms'] * 1e-3) / 1e9

@@ -225,10 +225,29 @@ def test_query_subrange_on_device(hip, oracle_built):
     assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d)
 
 
+def test_sample_keys_hold_more_tiles_than_one_range(hip, oracle_built):
+    """A sample key carries the index of its tile in 13 bits: a candidate range of more than 8192 sampled tiles is split
+    (here: 300k candidates with EVERY block sampled = 9375 tiles).  512 queries from the middle, against the oracle."""
+    import torch
+    n, d, k = 300000, 8, 15
+    x = np.random.default_rng(99).random((n, d), dtype=np.float32)
+    t = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    want_i, want_d = ko.knn(x, k, q_begin=150000, n_q=512)
+    try:
+        for splits, stride in [(0, 1), (1, 1), (0, 2), (0, 0)]:
+            hipknn.set_sample_layout(splits, stride)
+            idx, dist = hipknn.knn_graph_device(t.data_ptr(), n, d, k, q_begin=150000, n_q=512)
+            assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (splits, stride)
+            assert hipknn.last_fallback_count() < 64
+    finally:
+        hipknn.set_sample_layout(0, 0)
+
+
 @pytest.mark.parametrize('n,d,k,include_self', [(20000, 64, 15, False), (12000, 3, 15, True), (30000, 32, 50, False),
                                                   (9000, 8, 1, False), (16411, 17, 16, False)])
 def test_sampled_threshold_route(hip, oracle_built, n, d, k, include_self):
-    # large candidate sets take stage 1b (threshold from a 1/8 sample, then collect); the same
+    # large candidate sets take stage 1b (threshold from a sample of the candidate blocks, then collect); the same
     # inputs through the full select (stage 1a) must give the same bits
     rng = np.random.default_rng(n + d + k)
     x = rng.random((n, d), dtype=np.float32)
