@@ -881,8 +881,10 @@ __global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const unsigned 
   const int nreg = n / 64;
 #pragma unroll
   for (int j = 0; j < MAXR; ++j) key[j] = j < nreg ? skey[ql * n + j * 64 + lane] : 0xffffffffu;
+  // only the distance bits order the keys (bit 31 is clear, the low SKEY_BITS are the tile index): 18 steps; keys
+  // that agree with the m-th smallest in those bits are all taken
   unsigned prefix = 0;
-  for (int bit = 31; bit >= 0; --bit) {
+  for (int bit = 30; bit >= SKEY_BITS; --bit) {
     const unsigned trial = prefix | ((1u << bit) - 1u);
     int c = 0;
 #pragma unroll
@@ -890,6 +892,7 @@ __global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const unsigned 
       if (j < nreg) c += __builtin_popcountll(__ballot(key[j] <= trial));
     if (c < m) prefix |= 1u << bit;
   }
+  prefix |= SKEY_MASK;
   float worst = 0.f;
   if (prefix < 0x7f800000u) {   // the m-th smallest key is a real distance
     const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
