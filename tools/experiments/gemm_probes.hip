@@ -49,7 +49,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 // CC_GEMM_PACE=1 (experiment, off): workgroups that share panels are kept within a few K-steps of each
 // other (chunks of CC_GEMM_PACE_EVERY K-steps, at most CC_GEMM_PACE_LEAD + 1 chunks ahead of the slowest
-// member).  Measured on layer 1 (tools/pace_sweep.sh, tools/pmc_collect.sh): L2 hit rate 29 % -> 62 % (EVERY=8)
+// member).  Measured on layer 1 (tools/experiments/round1/pace_sweep.sh, pmc_collect.sh): L2 hit rate 29 % -> 62 % (EVERY=8)
 // / 81 % (EVERY=2), L2-miss traffic 33 -> 17.9 / 8.9 GB per launch, but 137.4 -> 134.7 / 128.5 TFLOP/s:
 // the misses are served on-die and are not on the critical path, while lock-step issue is slower.
 #ifndef CC_GEMM_PACE
@@ -83,7 +83,7 @@ static_assert(BN == 128 && (BK == 32 || BK == 64), "tile shape");
 __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
 #ifdef CC_GEMM_TRACE
-// diagnostic build only (tools/gemm_trace.py): per-workgroup wall-clock stamps of the layer-1 kernel
+// diagnostic build only (tools/experiments/round1/gemm_trace.py): per-workgroup wall-clock stamps of the layer-1 kernel
 __device__ unsigned long long g_gemm_trace[16384 * 4];
 #endif
 
