@@ -114,7 +114,7 @@ struct Encoder {
   float *h2_all = nullptr, *h3_all = nullptr, *h4_all = nullptr;
   // sparse first layer (cc_encoder_set_sparse_input): x @ K1 and the raw-input rows of K2 as CSR x dense products
   // on the vector ALUs; the whole call is one pass, so layer 1's output is kept for all rows too
-  bool low_latency = false;        // calls of <= 128 rows: layers 1-2 as split-K (gemm_small.hip)
+  bool low_latency = false;        // calls of <= 128 rows: layers 1-3 as split-K (gemm_small.hip)
   bool sparse = false;
   SpmmWeight S1, S2;
   PackedWeight L2a;                // cont: the hidden-activation rows of K2 (+ b2) for the dense MFMA part of layer 2
@@ -292,12 +292,12 @@ static int encode_csr_sparse(Encoder *e, Csr *c, int64_t row_start, int64_t n, f
     // layer 2 = sigmoid(h1 @ K2[:w0] + b2  (dense MFMA, linear)  +  x @ K2[w0:]  (sparse, adds the dense part, activates))
     if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, n, e->L2a, e->h2_all, e->ld2, ACT_LINEAR, CC_PROF_GEMM_L2))) return rc;
     if ((rc = launch_spmm(c->stream, row_start, n, e->S2, e->h2_all, e->ld2, e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_SPMM_L2, nnz_hint))) return rc;
-    if ((rc = launch_gemm(e->h2_all, e->ld2, nullptr, 0, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h2_all, e->ld2, nullptr, 0, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], e->h4_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h4_all, e->ld3, nullptr, 0, n, e->L[4], dev_out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   } else {
     if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, n, e->L[1], e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
-    if ((rc = launch_gemm(e->h2_all, e->ld2, e->h1_all, e->ld1, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h2_all, e->ld2, e->h1_all, e->ld1, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], dev_out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_row_softmax(dev_out, n, e->E, e->E))) return rc;
   }
@@ -355,14 +355,14 @@ static int encoder_forward16(Encoder *e, int sl, int64_t M, float *out, float *h
     s1[n1++] = {e->xh[sl], e->ldxh, 1, nt};
     if ((rc = launch_gemm16(s1, n1, M, e->L16[1], h2, nullptr, e->ld2, 0, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
     if (h2_dst) return CC_OK;
-    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], e->h4[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h4[sl], e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   } else {
     const GemmSeg16 s0[1] = {{e->xh[sl], e->ldxh, 0, nt}};
     if ((rc = launch_gemm16(s0, 1, M, e->L16[0], e->h1[sl], nullptr, e->ld1, 0, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
     if ((rc = launch_gemm(e->h1[sl], e->ld1, nullptr, 0, M, e->L[1], e->h2[sl], e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
-    if ((rc = launch_gemm(e->h2[sl], e->ld2, e->h1[sl], e->ld1, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h2[sl], e->ld2, e->h1[sl], e->ld1, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_row_softmax(out, M, e->E, e->E))) return rc;
   }
@@ -378,14 +378,14 @@ static int encoder_forward(Encoder *e, int sl, int64_t M, float *out, float *h2_
     if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h1[sl], e->ld1, e->x[sl], e->ldx, M, e->L[1], h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2, e->low_latency))) return rc;
     if (h2_dst) return CC_OK;
-    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], e->h4[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h4[sl], e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   } else {
     // reference src/bigan_classify.py:31-39: p → h → concat[h, p] → 150 → softmax(E)
     if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h1[sl], e->ld1, nullptr, 0, M, e->L[1], e->h2[sl], e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2, e->low_latency))) return rc;
-    if ((rc = launch_gemm(e->h2[sl], e->ld2, e->h1[sl], e->ld1, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h2[sl], e->ld2, e->h1[sl], e->ld1, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_row_softmax(out, M, e->E, e->E))) return rc;
   }
@@ -503,7 +503,7 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   g_cur = nullptr;
   if (dual) CC_HIP(hipStreamSynchronize(g_stream2));   // join before the tail / before returning
   if (tail_once) {
-    if ((rc = launch_gemm(e->h2_all, e->ld2, nullptr, 0, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = launch_gemm(e->h2_all, e->ld2, nullptr, 0, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], e->h4_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
     if ((rc = launch_gemm(e->h4_all, e->ld3, nullptr, 0, n, e->L[4], dev_out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
   }

@@ -48,24 +48,36 @@ __global__ __launch_bounds__(S_THREADS) void gemm_small_partial_kernel(
   for (int i = 0; i < MS; ++i) arow[i] = (i * 32 + r) < M ? (i * 32 + r) : M - 1;
   const f32x4 *wt = Wp + ((int64_t)n_tile * KT + kt0) * TILE_W_F4 + h * SBN + wave * 32 + r;
 
-  for (int kt = kt0; kt < kt1; ++kt) {
+  // operands of k-tile kt + 1 are loaded while the MFMAs of k-tile kt run (two register sets, ping-pong): with one
+  // set every wave sat out a full HBM round trip per k-tile (L1 at 128 rows: 347 us for 369 MB)
+  f32x4 b[2][4], a[2][MS][4];
+  auto load = [&](int kt, int set) {
     const bool seg1 = kt < KT1;                                      // wave-uniform
     const float *abase = seg1 ? A1 + (int64_t)kt * SBK : A2 + (int64_t)(kt - KT1) * SBK;
     const int64_t lda = seg1 ? lda1 : lda2;
-    f32x4 b[4], a[MS][4];
+    const f32x4 *w = wt + (int64_t)(kt - kt0) * TILE_W_F4;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) b[t] = wt[2 * t * SBN];              // k = 8t + 4h .. +3 of this lane's column
+    for (int t = 0; t < 4; ++t) b[set][t] = w[2 * t * SBN];          // k = 8t + 4h .. +3 of this lane's column
 #pragma unroll
     for (int i = 0; i < MS; ++i)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) a[i][t] = *reinterpret_cast<const f32x4 *>(abase + arow[i] * lda + 8 * t + 4 * h);
-    wt += TILE_W_F4;
+      for (int t = 0; t < 4; ++t) a[set][i][t] = *reinterpret_cast<const f32x4 *>(abase + arow[i] * lda + 8 * t + 4 * h);
+  };
+  if (kt0 < kt1) load(kt0, 0);
+  for (int kt = kt0; kt < kt1; kt += 2) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int u = 0; u < 2; ++u) {
+      if (kt + u < kt1) {                                            // wave-uniform
+        if (kt + u + 1 < kt1) load(kt + u + 1, u ^ 1);
 #pragma unroll
-      for (int u = 0; u < 4; ++u)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int i = 0; i < MS; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][t][u], b[t][u], acc[i], 0, 0, 0);
+          for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int i = 0; i < MS; ++i)
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i][t][v], b[u][t][v], acc[i], 0, 0, 0);
+      }
+    }
   }
 
   float *dst = partial + (int64_t)split * (MS * 32) * n_pad + n_tile * SBN + wave * 32 + r;
@@ -98,8 +110,9 @@ DevBuf g_partial;   // split-K partial sums; released by gemm_small_release (cc_
 void gemm_small_release() { g_partial.release(); }
 
 bool gemm_small_applies(int64_t M, const PackedWeight &W) {
-  // worth it when the tiled kernel would run a single m-tile over a long K; the tail layers (K <= 1650) stay tiled
-  return M >= 1 && M <= 128 && W.N > 0 && (W.KT1 + W.KT2) >= 64;
+  // worth it when the tiled kernel would run a single m-tile over a long K: layers 1-2 and the first tail layer
+  // (K = 1650: two workgroups walking 52 k-tiles took 120 us of a 0.43 ms call); the 150-wide layers stay tiled
+  return M >= 1 && M <= 128 && W.N > 0 && (W.KT1 + W.KT2) >= 16;
 }
 
 int launch_gemm_small(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M, const PackedWeight &W,
@@ -107,9 +120,10 @@ int launch_gemm_small(const float *A1, int64_t lda1, const float *A2, int64_t ld
   const int KT = (int)(W.KT1 + W.KT2), NT = (int)W.NT;
   const int MS = (int)ceil_div(M, 32), m_pad = MS * 32;
   const int64_t n_pad = (int64_t)NT * SBN;
-  // ~1024 workgroups, at least 8 k-tiles each
+  // ~1024 workgroups, at least 8 k-tiles each (4 for a short K)
+  const int min_kt = KT >= 256 ? 8 : 4;
   int nsplit = (int)ceil_div(1024, NT);
-  if (nsplit > KT / 8) nsplit = KT / 8 > 0 ? KT / 8 : 1;
+  if (nsplit > KT / min_kt) nsplit = KT / min_kt > 0 ? KT / min_kt : 1;
   const int kt_per_split = (int)ceil_div(KT, nsplit);
   nsplit = (int)ceil_div(KT, kt_per_split);
   int rc;
