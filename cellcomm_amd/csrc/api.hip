@@ -280,6 +280,8 @@ static int encoder_ensure_all_rows(Encoder *e, int64_t n, bool with_h1) {
   return CC_OK;
 }
 
+static int encoder_tail_cont(Encoder *e, const float *h2, int64_t M, float *h3, float *h4, float *out);
+
 // Sparse first layer: the whole range in one pass, no dense copy of the counts (reference graphs
 // src/bigan_cont.py:32-41, src/bigan_classify.py:31-39; see spmm.hip).
 static int encode_csr_sparse(Encoder *e, Csr *c, int64_t row_start, int64_t n, float *dev_out) {
@@ -292,9 +294,7 @@ static int encode_csr_sparse(Encoder *e, Csr *c, int64_t row_start, int64_t n, f
     // layer 2 = sigmoid(h1 @ K2[:w0] + b2  (dense MFMA, linear)  +  x @ K2[w0:]  (sparse, adds the dense part, activates))
     if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, n, e->L2a, e->h2_all, e->ld2, ACT_LINEAR, CC_PROF_GEMM_L2))) return rc;
     if ((rc = launch_spmm(c->stream, row_start, n, e->S2, e->h2_all, e->ld2, e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_SPMM_L2, nnz_hint))) return rc;
-    if ((rc = launch_gemm(e->h2_all, e->ld2, nullptr, 0, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
-    if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], e->h4_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h4_all, e->ld3, nullptr, 0, n, e->L[4], dev_out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = encoder_tail_cont(e, e->h2_all, n, e->h3_all, e->h4_all, dev_out))) return rc;
   } else {
     if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, n, e->L[1], e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
     if ((rc = launch_gemm(e->h2_all, e->ld2, e->h1_all, e->ld1, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
@@ -339,6 +339,17 @@ static int encoder_ensure_ws(Encoder *e, int64_t rows, int slots) {
   return CC_OK;
 }
 
+// Tail of the cont encoder (reference src/bigan_cont.py:38-41) on M rows of h2: three Dense + sigmoid layers.  Calls of
+// <= 128 rows of a low-latency encoder take the two-launch form of gemm_small.hip.
+static int encoder_tail_cont(Encoder *e, const float *h2, int64_t M, float *h3, float *h4, float *out) {
+  int rc;
+  if (e->low_latency && tail_small_applies(M, e->L[2], e->L[3], e->L[4]))
+    return launch_tail_small(h2, e->ld2, M, e->L[2], e->L[3], e->L[4], out, e->E, CC_PROF_GEMM_TAIL);
+  if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
+  if ((rc = launch_gemm(h3, e->ld3, nullptr, 0, M, e->L[3], h4, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+  return launch_gemm(h4, e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL);
+}
+
 // Layers 1-2 on the fp16 matrix cores from M rows already in e->xh[sl] (fp16); tail as fp32.
 static int encoder_forward16(Encoder *e, int sl, int64_t M, float *out, float *h2_dst = nullptr) {
   float *h2 = h2_dst ? h2_dst : e->h2[sl];   // h2_dst given: stop after layer 2 (the caller runs the tail)
@@ -355,9 +366,7 @@ static int encoder_forward16(Encoder *e, int sl, int64_t M, float *out, float *h
     s1[n1++] = {e->xh[sl], e->ldxh, 1, nt};
     if ((rc = launch_gemm16(s1, n1, M, e->L16[1], h2, nullptr, e->ld2, 0, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
     if (h2_dst) return CC_OK;
-    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
-    if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], e->h4[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h4[sl], e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = encoder_tail_cont(e, h2, M, e->h3[sl], e->h4[sl], out))) return rc;
   } else {
     const GemmSeg16 s0[1] = {{e->xh[sl], e->ldxh, 0, nt}};
     if ((rc = launch_gemm16(s0, 1, M, e->L16[0], e->h1[sl], nullptr, e->ld1, 0, ACT_SIGMOID, CC_PROF_GEMM_L1))) return rc;
@@ -378,9 +387,7 @@ static int encoder_forward(Encoder *e, int sl, int64_t M, float *out, float *h2_
     if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1, e->low_latency))) return rc;
     if ((rc = launch_gemm(e->h1[sl], e->ld1, e->x[sl], e->ldx, M, e->L[1], h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2, e->low_latency))) return rc;
     if (h2_dst) return CC_OK;
-    if ((rc = launch_gemm(h2, e->ld2, nullptr, 0, M, e->L[2], e->h3[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
-    if ((rc = launch_gemm(e->h3[sl], e->ld3, nullptr, 0, M, e->L[3], e->h4[sl], e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h4[sl], e->ld3, nullptr, 0, M, e->L[4], out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = encoder_tail_cont(e, h2, M, e->h3[sl], e->h4[sl], out))) return rc;
   } else {
     // reference src/bigan_classify.py:31-39: p → h → concat[h, p] → 150 → softmax(E)
     if ((rc = launch_gemm(e->x[sl], e->ldx, nullptr, 0, M, e->L[0], e->h1[sl], e->ld1, ACT_SIGMOID, CC_PROF_GEMM_L1, e->low_latency))) return rc;
@@ -503,9 +510,7 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   g_cur = nullptr;
   if (dual) CC_HIP(hipStreamSynchronize(g_stream2));   // join before the tail / before returning
   if (tail_once) {
-    if ((rc = launch_gemm(e->h2_all, e->ld2, nullptr, 0, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
-    if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], e->h4_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_gemm(e->h4_all, e->ld3, nullptr, 0, n, e->L[4], dev_out, e->E, ACT_SIGMOID, CC_PROF_GEMM_TAIL))) return rc;
+    if ((rc = encoder_tail_cont(e, e->h2_all, n, e->h3_all, e->h4_all, dev_out))) return rc;
   }
   CC_HIP(hipStreamSynchronize(stream()));
   return CC_OK;

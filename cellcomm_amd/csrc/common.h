@@ -117,6 +117,11 @@ int launch_row_softmax(float *X, int64_t M, int E, int64_t ld);
 bool gemm_small_applies(int64_t M, const PackedWeight &W);
 int launch_gemm_small(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M, const PackedWeight &W,
                       float *C, int64_t ldc, int act, int prof_class);
+// the whole tail of the cont encoder (three Dense + sigmoid layers, the last two <= 160 wide) for <= 128 rows in two
+// launches: split-K partials of the first, then reduce + both remaining layers fused (same opt-in as above)
+bool tail_small_applies(int64_t M, const PackedWeight &W3, const PackedWeight &W4, const PackedWeight &W5);
+int launch_tail_small(const float *A, int64_t lda, int64_t M, const PackedWeight &W3, const PackedWeight &W4,
+                      const PackedWeight &W5, float *out, int64_t ldo, int prof_class);
 void gemm_small_release();
 
 // gemm16.hip — layers 1/2 on the fp16 matrix cores (CC_DTYPE_F16 / CC_DTYPE_F16X2)

@@ -103,6 +103,111 @@ __global__ void gemm_small_reduce_kernel(const float *__restrict__ partial, int 
   C[(int64_t)m * ldc + n] = act == ACT_SIGMOID ? 1.0f / (1.0f + expf(-z)) : (act == ACT_RELU ? fmaxf(z, 0.f) : z);
 }
 
+// The tail of the cont encoder for <= 128 rows in one launch (reference src/bigan_cont.py:38-41): the split-K partial
+// sums of the first tail layer are reduced in a fixed order (+ bias, sigmoid) into LDS, then two more Dense + sigmoid
+// layers of <= 160 inputs run out of LDS with their packed weights read straight from L2.  One workgroup per 32 rows;
+// wave w owns columns [32w, 32w + 32) of every 128-column tile.  As separate tiled launches the two 150-wide layers
+// took ~27 us each (5 k-tiles behind two barriers apiece) plus the reduce kernel of the layer before.
+constexpr int TS_LD = 164;   // floats per LDS row: 160 inputs + 4 (16-byte reads of 32 rows spread over the banks)
+
+__device__ __forceinline__ float ts_sigmoid(float z) { return 1.0f / (1.0f + expf(-z)); }
+
+constexpr int TS_KT = 5;     // k-tiles of a fused layer (<= 160 inputs)
+
+// the B fragments of one 128-column weight tile for all its k-tiles, in flight together (one L2 round trip per tile
+// instead of one per k-tile: a single workgroup has nothing else to hide them behind)
+__device__ __forceinline__ void ts_load_w(const f32x4 *__restrict__ Wp, int nt, int KT, f32x4 (&bw)[TS_KT][4], int lane,
+                                          int wave) {
+  const int r = lane & 31, h = lane >> 5;
+  const f32x4 *wt = Wp + (int64_t)nt * KT * TILE_W_F4 + h * SBN + wave * 32 + r;
+#pragma unroll
+  for (int kt = 0; kt < TS_KT; ++kt)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) bw[kt][t] = wt[(kt < KT ? kt : 0) * TILE_W_F4 + 2 * t * SBN];
+}
+
+// columns [128 nt + 32 wave, +32) of sigmoid(src[32][TS_LD] @ W + bias): into LDS rows (0 beyond N, up to kcols_out
+// columns) or, for the last layer, into the output rows
+__device__ __forceinline__ void ts_tile(const float *src, const f32x4 (&bw)[TS_KT][4], const float *__restrict__ bias,
+                                        int nt, int KT, int N, float *dst_lds, int kcols_out, float *dst_glob,
+                                        int64_t ldo, int rows_valid, int lane, int wave) {
+  const int r = lane & 31, h = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+  for (int kt = 0; kt < TS_KT; ++kt) {
+    if (kt < KT) {
+      f32x4 a[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) a[t] = *reinterpret_cast<const f32x4 *>(src + r * TS_LD + kt * SBK + 8 * t + 4 * h);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][u], bw[kt][t][u], acc, 0, 0, 0);
+    }
+  }
+  const int col = nt * SBN + wave * 32 + r;
+  const float bv = col < N ? bias[col] : 0.f;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+    const float v = col < N ? ts_sigmoid(acc[e] + bv) : 0.f;
+    if (dst_lds) {
+      if (col < kcols_out) dst_lds[row * TS_LD + col] = v;
+    } else if (col < N && row < rows_valid) {
+      dst_glob[(int64_t)row * ldo + col] = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(S_THREADS) void tail_small_fused_kernel(
+    const float *__restrict__ partial, int nsplit, int m_pad, int64_t n_pad, int M, const float *__restrict__ bias3,
+    int N3, const f32x4 *__restrict__ W4, const float *__restrict__ bias4, int KT4, int NT4, int N4,
+    const f32x4 *__restrict__ W5, const float *__restrict__ bias5, int KT5, int NT5, int N5, float *__restrict__ out,
+    int64_t ldo) {
+  __shared__ __attribute__((aligned(16))) float hA[32 * TS_LD];
+  __shared__ __attribute__((aligned(16))) float hB[32 * TS_LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int row0 = blockIdx.x * 32;
+  // the weights do not depend on anything computed here: all of layer 4's and the first tile of layer 5's are
+  // requested before the reduction below starts
+  f32x4 w4a[TS_KT][4], w4b[TS_KT][4], w5a[TS_KT][4];
+  ts_load_w(W4, 0, KT4, w4a, lane, wave);
+  ts_load_w(W4, NT4 > 1 ? 1 : 0, KT4, w4b, lane, wave);
+  ts_load_w(W5, 0, KT5, w5a, lane, wave);
+  // layer 3's output: fixed-order sum of the split-K partials, bias, sigmoid; zero beyond its N3 columns.  A thread
+  // owns one column of several rows; the partials of a row are requested 16 at a time.
+  const int kc = KT4 * SBK;
+  for (int i = tid; i < 32 * kc; i += S_THREADS) {
+    const int row = i / kc, col = i - row * kc;
+    float v = 0.f;
+    if (col < N3) {
+      const float *p = partial + (int64_t)(row0 + row) * n_pad + col;
+      const int64_t step = (int64_t)m_pad * n_pad;
+      float z = 0.f;
+      for (int s0 = 0; s0 < nsplit; s0 += 16) {
+        float q[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q[j] = s0 + j < nsplit ? p[(s0 + j) * step] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) z += q[j];   // split order 0, 1, 2, ...: adding the 0.f of absent splits changes nothing
+      }
+      v = ts_sigmoid(z + bias3[col]);
+    }
+    hA[row * TS_LD + col] = v;
+  }
+  __syncthreads();
+  ts_tile(hA, w4a, bias4, 0, KT4, N4, hB, KT5 * SBK, nullptr, 0, 0, lane, wave);
+  if (NT4 > 1) ts_tile(hA, w4b, bias4, 1, KT4, N4, hB, KT5 * SBK, nullptr, 0, 0, lane, wave);
+  __syncthreads();
+  ts_tile(hB, w5a, bias5, 0, KT5, N5, nullptr, 0, out + (int64_t)row0 * ldo, ldo, M - row0, lane, wave);
+  if (NT5 > 1) {
+    ts_load_w(W5, 1, KT5, w4a, lane, wave);
+    ts_tile(hB, w4a, bias5, 1, KT5, N5, nullptr, 0, out + (int64_t)row0 * ldo, ldo, M - row0, lane, wave);
+  }
+}
+
 DevBuf g_partial;   // split-K partial sums; released by gemm_small_release (cc_shutdown)
 
 }  // namespace
@@ -115,8 +220,9 @@ bool gemm_small_applies(int64_t M, const PackedWeight &W) {
   return M >= 1 && M <= 128 && W.N > 0 && (W.KT1 + W.KT2) >= 16;
 }
 
-int launch_gemm_small(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M, const PackedWeight &W,
-                      float *C, int64_t ldc, int act, int prof_class) {
+// the split-K partial sums of act-less A @ W into g_partial; *nsplit_out / *m_pad_out / *n_pad_out describe its layout
+static int launch_partial(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M, const PackedWeight &W,
+                          int *nsplit_out, int *m_pad_out, int64_t *n_pad_out) {
   const int KT = (int)(W.KT1 + W.KT2), NT = (int)W.NT;
   const int MS = (int)ceil_div(M, 32), m_pad = MS * 32;
   const int64_t n_pad = (int64_t)NT * SBN;
@@ -128,7 +234,6 @@ int launch_gemm_small(const float *A1, int64_t lda1, const float *A2, int64_t ld
   nsplit = (int)ceil_div(KT, kt_per_split);
   int rc;
   if ((rc = g_partial.alloc(sizeof(float) * (size_t)nsplit * (size_t)m_pad * (size_t)n_pad))) return rc;
-  ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
   const f32x4 *wp = reinterpret_cast<const f32x4 *>(W.d_w);
 #define CC_SMALL(MSV)                                                                                              \
   hipLaunchKernelGGL(gemm_small_partial_kernel<MSV>, dim3((unsigned)(NT * nsplit)), dim3(S_THREADS), 0, stream(), A1, \
@@ -141,9 +246,42 @@ int launch_gemm_small(const float *A1, int64_t lda1, const float *A2, int64_t ld
   }
 #undef CC_SMALL
   CC_HIP(hipGetLastError());
+  *nsplit_out = nsplit;
+  *m_pad_out = m_pad;
+  *n_pad_out = n_pad;
+  return CC_OK;
+}
+
+int launch_gemm_small(const float *A1, int64_t lda1, const float *A2, int64_t lda2, int64_t M, const PackedWeight &W,
+                      float *C, int64_t ldc, int act, int prof_class) {
+  ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
+  int nsplit, m_pad, rc;
+  int64_t n_pad;
+  if ((rc = launch_partial(A1, lda1, A2, lda2, M, W, &nsplit, &m_pad, &n_pad))) return rc;
   const int64_t total = M * W.N;
   hipLaunchKernelGGL(gemm_small_reduce_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, stream(),
                      g_partial.as<float>(), nsplit, m_pad, n_pad, (int)M, (int)W.N, W.d_bias, C, ldc, act);
+  CC_HIP(hipGetLastError());
+  return CC_OK;
+}
+
+bool tail_small_applies(int64_t M, const PackedWeight &W3, const PackedWeight &W4, const PackedWeight &W5) {
+  // layer 3 by split-K, layers 4 and 5 out of LDS: single-segment Dense layers of <= 160 inputs
+  return gemm_small_applies(M, W3) && W3.N <= 5 * SBK && W4.K2 == 0 && W5.K2 == 0 && W4.K1 == W3.N && W5.K1 == W4.N &&
+         W4.N <= 5 * SBK && W4.KT1 <= 5 && W5.KT1 <= 5 && W5.N > 0;
+}
+
+int launch_tail_small(const float *A, int64_t lda, int64_t M, const PackedWeight &W3, const PackedWeight &W4,
+                      const PackedWeight &W5, float *out, int64_t ldo, int prof_class) {
+  ProfScope prof(prof_class, 2.0 * (double)M * ((double)(W3.K1 + W3.K2) * (double)W3.N + (double)W4.K1 * (double)W4.N +
+                                                 (double)W5.K1 * (double)W5.N));
+  int nsplit, m_pad, rc;
+  int64_t n_pad;
+  if ((rc = launch_partial(A, lda, nullptr, 0, M, W3, &nsplit, &m_pad, &n_pad))) return rc;
+  hipLaunchKernelGGL(tail_small_fused_kernel, dim3((unsigned)(m_pad / 32)), dim3(S_THREADS), 0, stream(),
+                     g_partial.as<float>(), nsplit, m_pad, n_pad, (int)M, W3.d_bias, (int)W3.N,
+                     reinterpret_cast<const f32x4 *>(W4.d_w), W4.d_bias, (int)W4.KT1, (int)W4.NT, (int)W4.N,
+                     reinterpret_cast<const f32x4 *>(W5.d_w), W5.d_bias, (int)W5.KT1, (int)W5.NT, (int)W5.N, out, ldo);
   CC_HIP(hipGetLastError());
   return CC_OK;
 }
