@@ -100,9 +100,9 @@ class HipEncoder:
             if dtype != 'f32':
                 raise ValueError('sparse=True computes in fp32: use dtype="f32"')
             _lib.check(lib.cc_encoder_set_sparse_input(self._h, 1))
-        # low_latency=True: calls of <= 128 rows (keras predict batches of 32, minibatches of 128) run the two big
-        # fp32 layers split-K over the whole chip; results stay within the same tolerance and are reproducible, but
-        # are no longer bit-identical to the same rows inside a larger call
+        # low_latency=True: calls of <= 128 rows (keras predict batches of 32, minibatches of 128) run the long-K
+        # fp32 layers split-K over the whole chip (and the narrow tail in one launch); results stay within the same
+        # tolerance and are reproducible, but are no longer bit-identical to the same rows inside a larger call
         self.low_latency = bool(low_latency)
         if self.low_latency:
             _lib.check(lib.cc_encoder_set_low_latency(self._h, 1))

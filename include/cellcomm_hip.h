@@ -91,9 +91,10 @@ int cc_encoder_set_batch(void *enc, int64_t batch_rows);
 int cc_encoder_set_sparse_input(void *enc, int on);
 /* Low-latency form for small calls (default off).  The reference calls predict on batches of 32 (keras default,
  * reference src/bigan_basic.py:30) and minibatches of 128 (src/__main__.py:44): with one row tile the two big
- * fp32 layers otherwise walk K = 30000 in 24 / 12 workgroups.  When on, calls of <= 128 rows run them split-K over
- * ~1024 workgroups with a fixed-order reduction: same fp32 arithmetic and tolerance, reproducible call to call,
- * but a row's result is then no longer bit-identical to the same row inside a larger call (off keeps that invariant). */
+ * fp32 layers otherwise walk K = 30000 in 24 / 12 workgroups.  When on, calls of <= 128 rows run them (and the first
+ * of the narrow layers behind them) split-K over ~1024 workgroups with a fixed-order reduction, and the cont
+ * encoder's last two layers in one launch: same fp32 arithmetic and tolerance, reproducible call to call, but a
+ * row's result is then no longer bit-identical to the same row inside a larger call (off keeps that invariant). */
 int cc_encoder_set_low_latency(void *enc, int on);
 /* fp16 dtypes: passes of the last cc_encode* call that ran on the fp32 kernels instead — CC_DTYPE_F16X2:
  * some value of the pass is not exactly an fp16 number; CC_DTYPE_F16: some value lies outside the fp16
