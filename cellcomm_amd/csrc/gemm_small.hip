@@ -48,27 +48,32 @@ __global__ __launch_bounds__(S_THREADS) void gemm_small_partial_kernel(
   for (int i = 0; i < MS; ++i) arow[i] = (i * 32 + r) < M ? (i * 32 + r) : M - 1;
   const f32x4 *wt = Wp + ((int64_t)n_tile * KT + kt0) * TILE_W_F4 + h * SBN + wave * 32 + r;
 
-  // operands of k-tile kt + 1 are loaded while the MFMAs of k-tile kt run (two register sets, ping-pong): with one
-  // set every wave sat out a full HBM round trip per k-tile (L1 at 128 rows: 347 us for 369 MB)
-  f32x4 b[2][4], a[2][MS][4];
+  // The operands of the next BD - 1 k-tiles are in flight while the MFMAs of the current one run (a ring of BD register
+  // sets for the weights AND the activations: loads complete in order, so an activation fragment requested after a
+  // later weight fragment would make the wave wait for both).  With one set every wave sat out a full HBM round trip
+  // per k-tile (layer 1 at 128 rows: 347 us for 369 MB); under this load a round trip takes ~5 us.
+  constexpr int BD = MS <= 2 ? 4 : 2;
+  f32x4 b[BD][4], a[BD][MS][4];
   auto load = [&](int kt, int set) {
-    const bool seg1 = kt < KT1;                                      // wave-uniform
-    const float *abase = seg1 ? A1 + (int64_t)kt * SBK : A2 + (int64_t)(kt - KT1) * SBK;
-    const int64_t lda = seg1 ? lda1 : lda2;
     const f32x4 *w = wt + (int64_t)(kt - kt0) * TILE_W_F4;
 #pragma unroll
     for (int t = 0; t < 4; ++t) b[set][t] = w[2 * t * SBN];          // k = 8t + 4h .. +3 of this lane's column
+    const bool seg1 = kt < KT1;                                      // wave-uniform
+    const float *abase = seg1 ? A1 + (int64_t)kt * SBK : A2 + (int64_t)(kt - KT1) * SBK;
+    const int64_t lda = seg1 ? lda1 : lda2;
 #pragma unroll
     for (int i = 0; i < MS; ++i)
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[set][i][t] = *reinterpret_cast<const f32x4 *>(abase + arow[i] * lda + 8 * t + 4 * h);
   };
-  if (kt0 < kt1) load(kt0, 0);
-  for (int kt = kt0; kt < kt1; kt += 2) {
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
+  for (int p = 0; p < BD - 1; ++p)
+    if (kt0 + p < kt1) load(kt0 + p, p);
+  for (int kt = kt0; kt < kt1; kt += BD) {
+#pragma unroll
+    for (int u = 0; u < BD; ++u) {
       if (kt + u < kt1) {                                            // wave-uniform
-        if (kt + u + 1 < kt1) load(kt + u + 1, u ^ 1);
+        if (kt + u + BD - 1 < kt1) load(kt + u + BD - 1, (u + BD - 1) % BD);
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -97,8 +102,17 @@ __global__ void gemm_small_reduce_kernel(const float *__restrict__ partial, int 
   const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= (int64_t)M * N) return;
   const int m = (int)(t / N), n = (int)(t % N);
+  // the partials of 16 splits are requested together, then added in split order
+  const float *p = partial + (int64_t)m * n_pad + n;
+  const int64_t step = (int64_t)m_pad * n_pad;
   float z = 0.f;
-  for (int s = 0; s < nsplit; ++s) z += partial[((int64_t)s * m_pad + m) * n_pad + n];
+  for (int s0 = 0; s0 < nsplit; s0 += 16) {
+    float q[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) q[j] = s0 + j < nsplit ? p[(s0 + j) * step] : 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) z += q[j];   // + 0.f for absent splits changes nothing
+  }
   z += bias[n];
   C[(int64_t)m * ldc + n] = act == ACT_SIGMOID ? 1.0f / (1.0f + expf(-z)) : (act == ACT_RELU ? fmaxf(z, 0.f) : z);
 }
@@ -179,23 +193,33 @@ __global__ __launch_bounds__(S_THREADS) void tail_small_fused_kernel(
   // layer 3's output: fixed-order sum of the split-K partials, bias, sigmoid; zero beyond its N3 columns.  A thread
   // owns one column of several rows; the partials of a row are requested 16 at a time.
   const int kc = KT4 * SBK;
-  for (int i = tid; i < 32 * kc; i += S_THREADS) {
-    const int row = i / kc, col = i - row * kc;
-    float v = 0.f;
-    if (col < N3) {
-      const float *p = partial + (int64_t)(row0 + row) * n_pad + col;
-      const int64_t step = (int64_t)m_pad * n_pad;
-      float z = 0.f;
-      for (int s0 = 0; s0 < nsplit; s0 += 16) {
-        float q[16];
+  const int64_t step = (int64_t)m_pad * n_pad;
+  for (int i0 = tid; i0 < 32 * kc; i0 += 4 * S_THREADS) {
+    float q[4][16];
+    int rowv[4], colv[4];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) q[j] = s0 + j < nsplit ? p[(s0 + j) * step] : 0.f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) z += q[j];   // split order 0, 1, 2, ...: adding the 0.f of absent splits changes nothing
-      }
-      v = ts_sigmoid(z + bias3[col]);
+    for (int c = 0; c < 4; ++c) {
+      const int i = i0 + c * S_THREADS;
+      rowv[c] = i / kc;
+      colv[c] = i - rowv[c] * kc;
     }
-    hA[row * TS_LD + col] = v;
+    float z[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < nsplit; s0 += 16) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const bool live = rowv[c] < 32 && colv[c] < N3;
+        const float *p = partial + (int64_t)(row0 + (live ? rowv[c] : 0)) * n_pad + (live ? colv[c] : 0);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) q[c][j] = live && s0 + j < nsplit ? p[(s0 + j) * step] : 0.f;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) z[c] += q[c][j];   // split order 0, 1, 2, ...; + 0.f for absent splits changes nothing
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+      if (rowv[c] < 32) hA[rowv[c] * TS_LD + colv[c]] = colv[c] < N3 ? ts_sigmoid(z[c] + bias3[colv[c]]) : 0.f;
   }
   __syncthreads();
   ts_tile(hA, w4a, bias4, 0, KT4, N4, hB, KT5 * SBK, nullptr, 0, 0, lane, wave);
@@ -226,9 +250,12 @@ static int launch_partial(const float *A1, int64_t lda1, const float *A2, int64_
   const int KT = (int)(W.KT1 + W.KT2), NT = (int)W.NT;
   const int MS = (int)ceil_div(M, 32), m_pad = MS * 32;
   const int64_t n_pad = (int64_t)NT * SBN;
-  // ~1024 workgroups, at least 8 k-tiles each (4 for a short K)
+  // As many workgroups as are resident at once and no more: by its registers the 32-row kernel runs 3 workgroups per
+  // CU, the others 2 (a wave per SIMD each) — 43 x 24 = 1032 workgroups on 1024 slots ran a second round for 8 of them
+  // (layer 1 of a 32-row call: 106 us instead of 60).  At least 8 k-tiles each (4 for a short K).
+  const int slots = 256 * (MS == 1 ? 3 : 2);
   const int min_kt = KT >= 256 ? 8 : 4;
-  int nsplit = (int)ceil_div(1024, NT);
+  int nsplit = slots / NT > 0 ? slots / NT : 1;
   if (nsplit > KT / min_kt) nsplit = KT / min_kt > 0 ? KT / min_kt : 1;
   const int kt_per_split = (int)ceil_div(KT, nsplit);
   nsplit = (int)ceil_div(KT, kt_per_split);
