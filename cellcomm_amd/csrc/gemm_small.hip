@@ -24,17 +24,19 @@ constexpr int SBN = GEMM_BN;                    // 128 columns per packed n-tile
 constexpr int S_THREADS = 256;                  // 4 waves, 32 columns each
 constexpr int TILE_W_F4 = (SBK / 4) * SBN;      // float4 per packed W tile
 
-// partial[split][m][n_pad] = A[:, k-range] @ W[k-range, :]   (MS = 32-row blocks of A: 1..4)
+// partial[split][m][n_pad] = A[:, k-tiles of the split] @ W[those k-tiles, :]   (MS = 32-row blocks of A: 1..4)
 template <int MS>
 __global__ __launch_bounds__(S_THREADS) void gemm_small_partial_kernel(
     const float *__restrict__ A1, int64_t lda1, const float *__restrict__ A2, int64_t lda2, int M,
-    const f32x4 *__restrict__ Wp, int KT1, int KT, int NT, int nsplit, int kt_per_split, float *__restrict__ partial,
+    const f32x4 *__restrict__ Wp, int KT1, int KT, int NT, int nsplit, float *__restrict__ partial,
     int64_t n_pad) {
   const int n_tile = blockIdx.x % NT, split = blockIdx.x / NT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
-  const int kt0 = split * kt_per_split;
-  const int kt1 = kt0 + kt_per_split < KT ? kt0 + kt_per_split : KT;
+  // split s takes k-tiles s, s + nsplit, s + 2 nsplit, ...: the workgroups of an n-tile, which run side by side, read
+  // ONE advancing window of the packed weights (nsplit x 16 KB) instead of nsplit far-apart streams that keep
+  // evicting each other's DRAM pages
+  const int nk = split < KT ? (KT - split + nsplit - 1) / nsplit : 0;
 
   f32x16 acc[MS];
 #pragma unroll
@@ -46,7 +48,7 @@ __global__ __launch_bounds__(S_THREADS) void gemm_small_partial_kernel(
   int arow[MS];
 #pragma unroll
   for (int i = 0; i < MS; ++i) arow[i] = (i * 32 + r) < M ? (i * 32 + r) : M - 1;
-  const f32x4 *wt = Wp + ((int64_t)n_tile * KT + kt0) * TILE_W_F4 + h * SBN + wave * 32 + r;
+  const f32x4 *wt = Wp + ((int64_t)n_tile * KT + split) * TILE_W_F4 + h * SBN + wave * 32 + r;
 
   // The operands of the next BD - 1 k-tiles are in flight while the MFMAs of the current one run (a ring of BD register
   // sets for the weights AND the activations: loads complete in order, so an activation fragment requested after a
@@ -54,10 +56,11 @@ __global__ __launch_bounds__(S_THREADS) void gemm_small_partial_kernel(
   // per k-tile (layer 1 at 128 rows: 347 us for 369 MB); under this load a round trip takes ~5 us.
   constexpr int BD = MS <= 2 ? 4 : 2;
   f32x4 b[BD][4], a[BD][MS][4];
-  auto load = [&](int kt, int set) {
-    const f32x4 *w = wt + (int64_t)(kt - kt0) * TILE_W_F4;
+  auto load = [&](int j, int set) {                                  // j-th k-tile of this split
+    const int kt = split + j * nsplit;
+    const f32x4 *w = wt + (int64_t)j * nsplit * TILE_W_F4;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) b[set][t] = w[2 * t * SBN];          // k = 8t + 4h .. +3 of this lane's column
+    for (int t = 0; t < 4; ++t) b[set][t] = __builtin_nontemporal_load(w + 2 * t * SBN);   // k = 8t + 4h .. +3 of this lane's column; read once: no cache allocation
     const bool seg1 = kt < KT1;                                      // wave-uniform
     const float *abase = seg1 ? A1 + (int64_t)kt * SBK : A2 + (int64_t)(kt - KT1) * SBK;
     const int64_t lda = seg1 ? lda1 : lda2;
@@ -66,21 +69,48 @@ __global__ __launch_bounds__(S_THREADS) void gemm_small_partial_kernel(
 #pragma unroll
       for (int t = 0; t < 4; ++t) a[set][i][t] = *reinterpret_cast<const f32x4 *>(abase + arow[i] * lda + 8 * t + 4 * h);
   };
+  if constexpr (MS <= 2) {
+    // Bandwidth-bound forms (<= 64 rows).  Straight-line loop body: every load is issued unconditionally (past the
+    // split's last k-tile it re-reads that tile) and a k-tile past the end is multiplied by zero instead of being
+    // branched around — with branches in the body the compiler's wait-count insertion fell back to s_waitcnt vmcnt(0)
+    // right after issuing the newest loads, i.e. no prefetch at all.
+    const int last = nk > 0 ? nk - 1 : 0;
 #pragma unroll
-  for (int p = 0; p < BD - 1; ++p)
-    if (kt0 + p < kt1) load(kt0 + p, p);
-  for (int kt = kt0; kt < kt1; kt += BD) {
+    for (int p = 0; p < BD - 1; ++p) load(p < last ? p : last, p);
+    __builtin_amdgcn_sched_barrier(0);
+    for (int j = 0; j < nk; j += BD) {
 #pragma unroll
-    for (int u = 0; u < BD; ++u) {
-      if (kt + u < kt1) {                                            // wave-uniform
-        if (kt + u + BD - 1 < kt1) load(kt + u + BD - 1, (u + BD - 1) % BD);
+      for (int u = 0; u < BD; ++u) {
+        const int jn = j + u + BD - 1;
+        load(jn < last ? jn : last, (u + BD - 1) % BD);
+        __builtin_amdgcn_sched_barrier(0);                           // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
+        const float live = j + u < nk ? 1.f : 0.f;                   // wave-uniform
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
           for (int v = 0; v < 4; ++v)
 #pragma unroll
             for (int i = 0; i < MS; ++i)
-              acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i][t][v], b[u][t][v], acc[i], 0, 0, 0);
+              acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i][t][v], b[u][t][v] * live, acc[i], 0, 0, 0);
+      }
+    }
+  } else {
+    // MFMA-bound forms (65-128 rows: 48-64 MFMAs of 64 cycles per k-tile): two waves per SIMD cover each other's
+    // loads; the plain ping-pong measured faster here (0.45 vs 0.54 ms per 128-row call) than the form above
+    if (nk > 0) load(0, 0);
+    for (int j = 0; j < nk; j += 2) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (j + u < nk) {                                            // wave-uniform
+          if (j + u + 1 < nk) load(j + u + 1, u ^ 1);
+#pragma unroll
+          for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+#pragma unroll
+              for (int i = 0; i < MS; ++i)
+                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][i][t][v], b[u][t][v], acc[i], 0, 0, 0);
+        }
       }
     }
   }
@@ -257,14 +287,12 @@ static int launch_partial(const float *A1, int64_t lda1, const float *A2, int64_
   const int min_kt = KT >= 256 ? 8 : 4;
   int nsplit = slots / NT > 0 ? slots / NT : 1;
   if (nsplit > KT / min_kt) nsplit = KT / min_kt > 0 ? KT / min_kt : 1;
-  const int kt_per_split = (int)ceil_div(KT, nsplit);
-  nsplit = (int)ceil_div(KT, kt_per_split);
   int rc;
   if ((rc = g_partial.alloc(sizeof(float) * (size_t)nsplit * (size_t)m_pad * (size_t)n_pad))) return rc;
   const f32x4 *wp = reinterpret_cast<const f32x4 *>(W.d_w);
 #define CC_SMALL(MSV)                                                                                              \
   hipLaunchKernelGGL(gemm_small_partial_kernel<MSV>, dim3((unsigned)(NT * nsplit)), dim3(S_THREADS), 0, stream(), A1, \
-                     lda1, A2, lda2, (int)M, wp, (int)W.KT1, KT, NT, nsplit, kt_per_split, g_partial.as<float>(), n_pad)
+                     lda1, A2, lda2, (int)M, wp, (int)W.KT1, KT, NT, nsplit, g_partial.as<float>(), n_pad)
   switch (MS) {
     case 1: CC_SMALL(1); break;
     case 2: CC_SMALL(2); break;
