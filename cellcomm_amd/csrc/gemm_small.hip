@@ -2,7 +2,7 @@
 // predict, reference src/bigan_basic.py:30) and minibatches of 128 (src/__main__.py:44).  With one m-tile the tiled
 // kernel of gemm.hip has 24 (layer 1) / 12 (layer 2) workgroups, each walking K = 30000 alone: 1.5-3 ms of latency for
 // a layer that only has to stream its weights once (369 MB: ~0.1 ms of HBM time).  Here the K range is split over
-// ~1024 workgroups instead (split-K), every workgroup streams its slice of the SAME packed weight tiles straight
+// the resident workgroup slots instead (split-K: 500-770 workgroups, k-tiles dealt round-robin), every workgroup streams its share of the SAME packed weight tiles straight
 // from HBM into MFMA operands (no LDS: a B fragment is one coalesced 16-byte load per lane, an A fragment one
 // 16-byte load from the L2-resident activations), and a second small kernel adds the partial sums in a FIXED
 // order (deterministic, bit-reproducible) and applies bias + activation.
