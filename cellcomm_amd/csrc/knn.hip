@@ -19,12 +19,13 @@
 //     filters the accumulator registers; survivors are appended to a per-query
 //     LDS list with a wavefront-local atomic, and a list that could overflow is
 //     compacted by the wave (rank-by-counting on 64-bit (dist,idx) keys).
-//     Large inputs take the cheaper route 1b: `select` runs on a 1/8 sample of the
-//     candidate blocks only and yields a per-query threshold T (the m-th best of the
-//     sample, so that ~8m candidates lie below it); `collect` then streams ALL
-//     candidates through the same MFMA tiles and appends everything with approximate
-//     distance <= T to a per-query buffer — no lists, no compaction, and freely split
-//     over candidate ranges (one range per XCD keeps its panels in that XCD's L2).
+//     Inputs beyond a few hundred candidates take route 1b (the product route): a SAMPLE pass over every 3rd-8th
+//     candidate block yields a per-query threshold T under which at least m >= k candidates lie (per-slot minima of
+//     a coarse fp16 tile + direct fp32 re-evaluation of the m best: knn_sample16_kernel / knn_slot_threshold_kernel);
+//     the COLLECT pass then streams ALL candidates through one fp16 product per pair with a rigorous error bound,
+//     re-evaluates the few pairs at or below T + bound directly in fp32 and appends those <= T to a per-query
+//     buffer (knn_collect16c_kernel) — no lists, no compaction, freely split over candidate ranges.  The fp32 tiles
+//     described above remain for d > 64, for data whose scale does not fit fp16, and as cross-checks behind options.
 //  2. rerank  — the K' survivors are re-scored in float64 exactly as the oracle
 //     does and ordered by (dist64, idx).  The result is CERTIFIED when the k-th
 //     exact distance is below τ_approx(K') − ε, ε a rigorous bound on the fp32
