@@ -17,8 +17,8 @@ as a CHILD process before this process touches torch or the GPU, relays rank 0's
 JSON line and exits with the child's status.
 """
 import argparse
+import ctypes
 import json
-import math
 import os
 import sys
 import time
@@ -373,12 +373,13 @@ def main():
         if knn_ms > 0:
             # algorithmic work of the search: 2 * queries * candidates * d.  Executed on the fp16 matrix
             # cores: ONE fp16 product per pair (hi x hi) + the norm step = ND + 1 MFMA K-steps of 16, by the collect
-            # pass over all candidates and by the sample pass over every S-th block (S as csrc/knn.hip chooses it)
+            # pass over all candidates and by the sample pass over every S-th block (S as the library chose it)
             knn_flop = 2.0 * (hi - lo) * args.cells * args.latent
             ktf = knn_flop / (knn_ms * 1e-3) / 1e12
             nd = -(-args.latent // 16)
-            m8 = max(16, -(-3 * args.k // 8))
-            stride = min(8, max(3, int(math.floor((args.cells / m8) ** 0.5 / 22.6 + 0.5)), -(-3 * args.k // 40)))
+            stat = ctypes.c_int64()
+            _lib.check(_lib.lib().cc_knn_stat(None, 2, ctypes.byref(stat)))   # CC_KNN_STAT_SAMPLE_STRIDE of the last search
+            stride = int(stat.value) or 8
             executed = 16.0 * (nd + 1) * (1.0 + 1.0 / stride) / args.latent
             line['roofline_knn'] = {'kernel': 'knn_sample16 + knn_collect16c + knn_merge + knn_rerank (per step)',
                                     'bound': 'mfma', 'achieved': ktf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',

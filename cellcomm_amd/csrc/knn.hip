@@ -1741,6 +1741,7 @@ struct KnnWorkspace {
   int sample_qw = 0;                       // 0 = chosen per call; 1 / 2 = query groups per wave of the fp16 sample pass
   int64_t last_fallback = 0;
   int64_t last_full_scan = 0;              // fallback queries that had to scan every candidate in float64 VALU
+  int64_t last_sample_stride = 0;          // sampling stride of the last search that took route 1b with a sample (else 0)
   void release() {
     DevBuf *all[] = {&P, &P16, &norms, &maxn, &keys, &cnts, &bound, &skeys, &scnts, &smin, &Tq, &cbuf, &ccur, &oidx, &odist,
                      &nflag, &flagged, &bnd_d, &bnd_i, &partial, &mu, &norm64, &max64, &plist, &pcnt, &nfull, &full_list, &part_d,
@@ -1899,6 +1900,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
   KnnWorkspace &ws = wsp ? *wsp : *knn_default_ws();
   ws.last_fallback = 0;
   ws.last_full_scan = 0;
+  ws.last_sample_stride = 0;
   CC_REQUIRE(N > 0 && N < (int64_t)2147483000, "knn: n_total=%lld out of range", (long long)N);
   CC_REQUIRE(d >= 1 && d <= 132, "knn: d=%d unsupported (1..132)", d);
   CC_REQUIRE(k >= 1 && k <= 128, "knn: k=%d unsupported (1..128)", k);
@@ -1961,6 +1963,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
   const bool collect_all = !ws.force_route_a && k <= CC_KNN_SAMPLED_MAXK && N <= col_cap;
   const bool sampled = collect_all || (!ws.force_route_a && NB >= CC_KNN_MIN_SBLK * SAMPLE &&
                                        N >= (int64_t)CC_KNN_MIN_SBLK * SAMPLE * m && k <= CC_KNN_SAMPLED_MAXK);
+  if (sampled && !collect_all) ws.last_sample_stride = SAMPLE;
 
   DevBuf &P = ws.P, &P16 = ws.P16, &norms = ws.norms, &maxn = ws.maxn, &keys = ws.keys, &cnts = ws.cnts,
          &bound = ws.bound, &skeys = ws.skeys, &scnts = ws.scnts, &smin = ws.smin, &Tq = ws.Tq, &cbuf = ws.cbuf, &ccur = ws.ccur,
@@ -2342,6 +2345,7 @@ int cc_knn_stat(void *knn, int stat, int64_t *value) {
   switch (stat) {
     case CC_KNN_STAT_FALLBACK_QUERIES: *value = ws->last_fallback; break;
     case CC_KNN_STAT_FULL_SCAN_QUERIES: *value = ws->last_full_scan; break;
+    case CC_KNN_STAT_SAMPLE_STRIDE: *value = ws->last_sample_stride; break;
     default: CC_REQUIRE(false, "unknown kNN statistic %d", stat);
   }
   return CC_OK;

@@ -90,6 +90,14 @@ def use_fp64_prefilter(on):
     _lib.check(_lib.lib().cc_knn_use_fp64_prefilter(1 if on else 0))
 
 
+def last_sample_stride():
+    """Every n-th candidate block fed the threshold of the last search (0: it ran without a sample pass)."""
+    import ctypes
+    out = ctypes.c_int64()
+    _lib.check(_lib.lib().cc_knn_stat(None, 2, ctypes.byref(out)))
+    return int(out.value)
+
+
 def last_full_scan_count():
     """Uncertified queries of the last call that had to scan every candidate in float64."""
     return int(_lib.lib().cc_knn_last_full_scan_count())

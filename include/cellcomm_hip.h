@@ -196,6 +196,7 @@ int cc_knn_search_dev(void *knn, const float *dev_x, int64_t n_total, int d, int
 int cc_knn_set_option(void *knn, int option, int value);
 #define CC_KNN_STAT_FALLBACK_QUERIES 0  /* queries of the last search that stage 2 could not certify   */
 #define CC_KNN_STAT_FULL_SCAN_QUERIES 1 /* of those, the ones that scanned ALL candidates in float64   */
+#define CC_KNN_STAT_SAMPLE_STRIDE 2     /* every n-th candidate block was sampled for the threshold (0: no sample pass) */
 int cc_knn_stat(void *knn, int stat, int64_t *value);
 
 /* Shorthands (ABI v101) for options / statistics of the default workspace. */

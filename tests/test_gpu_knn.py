@@ -255,12 +255,14 @@ def test_sampled_threshold_route(hip, oracle_built, n, d, k, include_self):
     qs = rng.choice(n, 300, replace=False)
     idx, dist = cc.knn_graph(x, k, include_self)
     n_fb = hipknn.last_fallback_count()
+    assert 3 <= hipknn.last_sample_stride() <= 8                                # route 1b ran, with a sample pass
     for q in qs:
         wi, wd = ko.knn(x, k, include_self, q_begin=int(q), n_q=1)
         assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0])
     hipknn.force_full_select(True)
     try:
         idx_a, dist_a = cc.knn_graph(x, k, include_self)
+        assert hipknn.last_sample_stride() == 0                                 # route 1a: no sample
     finally:
         hipknn.force_full_select(False)
     assert np.array_equal(idx, idx_a) and np.array_equal(dist, dist_a)
