@@ -31,8 +31,9 @@ sys.path.insert(0, ROOT)
 PEAK_F32_MFMA_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 matrix (= fp32 vector peak)
 PEAK_F16_MFMA_TFLOPS = 2500.0    # dense fp16/bf16 matrix
 PEAK_HBM_GBS = 8000.0
+PEAK_LDS_TBS = 157.3             # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz (the guide's LDS table; ~150 TB/s streaming)
 PCIE_GBS = 63.0                  # host link (spec), bounds the dense-host side numbers
-TRAFFIC_PROFILE = 'r02_pmc_hbm_traffic.json'   # tracked PMC summary that `roofline.traffic` is replayed from
+TRAFFIC_PROFILES = ('r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json')   # newest tracked PMC summary present   # tracked PMC summary that `roofline.traffic` is replayed from
 
 
 def baseline_metric():
@@ -57,10 +58,12 @@ def parse():
                     help='arithmetic of encoder layers 1-2: exact fp32 MFMA (default), fp16 operands, fp16 hi+lo split')
     ap.add_argument('--batch-rows', type=int, default=0, help='rows per pass through the layer stack (0 = library default)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-alt', action='store_true', help='skip the extra measurements reported under "alt" / "alt_sparse" / "dense_host"')
-    ap.add_argument('--dense-host', action='store_true',
-                    help='also measure the dense-host side numbers (cc_encode_dense throughput, batch-32/128 latency); off by '
-                         'default so that the per-kernel averages of a profiled default run are those of the timed passes')
+    ap.add_argument('--no-alt', action='store_true',
+                    help='skip the extra measurements reported under "alt" / "alt_f16" / "alt_sparse" / "dense_host"')
+    ap.add_argument('--no-dense-host', action='store_true',
+                    help='skip the dense-host side numbers (cc_encode_dense throughput, batch-32/128 latency); tools/profile_round.sh '
+                         'passes it so that the per-kernel averages of the profiled run are those of the timed passes')
+    ap.add_argument('--dense-host', action='store_true', help='(default now; kept for old command lines)')
     ap.add_argument('--sparse', action='store_true', help='make the sparse first layer (fp32 over the non-zeros) the measured path')
     ap.add_argument('--no-profile', action='store_true', help='diagnostic: no HIP events in the timed region')
     ap.add_argument('--cpu-sample-cells', type=int, default=8192)
@@ -68,7 +71,25 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(args, enc, local, enc_host):
+def workload_name(args, world):
+    """Which BASELINE.json config the arguments are (configs[i] as listed there), or 'custom'."""
+    shape = (args.cells, args.genes, args.latent, args.k, args.arch)
+    if shape == (100000, 30000, 64, 15, 'cont'):
+        return 'BASELINE configs[2]'
+    if shape[:3] == (10000, 20000, 32) and args.arch == 'cont':
+        return 'BASELINE configs[1] (its encode; this bench also builds the kNN graph)'
+    if shape == (1000000, 30000, 64, 15, 'cont'):
+        return 'BASELINE configs[3]' + ('' if world == 8 else f' on {world} GPU(s) instead of 8')
+    if shape == (125000, 30000, 64, 15, 'cont') and world == 1:
+        return "custom: one rank's encode share of BASELINE configs[3] (125k of 1M cells; kNN among these rows only)"
+    if shape == (500000, 33000, 64, 50, 'cont'):
+        return 'BASELINE configs[4]' + ('' if world == 8 and args.dtype == 'f16' else f' with dtype {args.dtype} on {world} GPU(s)')
+    if shape == (62500, 33000, 64, 50, 'cont') and world == 1:
+        return "custom: one rank's encode share of BASELINE configs[4] (62.5k of 500k cells; kNN among these rows only)"
+    return 'custom'
+
+
+def cpu_baseline(args, enc, local, enc_host, alt_samples=None):
     """The oracle (a CPU port of the path; the reference's TF code cannot run here or on the
     GPU box) timed on this host's cores on a bounded sample of the same workload."""
     import ctypes
@@ -95,6 +116,15 @@ def cpu_baseline(args, enc, local, enc_host):
     per_pair = t_knn / (nk * nk)
     per_cell = t_enc / ns + per_pair * args.cells
     rel = float(np.max(np.abs(out - enc_host[:ns]) / np.abs(out))) if local.row_ids() is None else None
+    # the other measured modes against the same CPU sample (the rows each timed leg left in host memory)
+    alt_rel = {}
+    for name, sample in (alt_samples or {}).items():
+        m = min(ns, len(sample))
+        alt_rel[name] = float(np.max(np.abs(out[:m] - sample[:m]) / np.abs(out[:m])))
+        if name == 'alt_f16':   # ... and against the float64 evaluation of ITS arithmetic: operands rounded to fp16 once
+            mf = min(128, m)
+            ref16 = eo.forward_f16(args.arch, ws, dense[:mf])
+            alt_rel['alt_f16_vs_f16_operand_oracle'] = float(np.max(np.abs(ref16 - sample[:mf]) / np.abs(ref16)))
     blas_threads = None
     try:
         from threadpoolctl import threadpool_info
@@ -112,6 +142,7 @@ def cpu_baseline(args, enc, local, enc_host):
         'encode_cells_per_s_batch32_like_keras_predict': 1.0 / t_b32,
         'knn_pairs_per_s': 1.0 / per_pair,
         'gpu_vs_cpu_sample_max_rel': rel,
+        'alt_max_rel': alt_rel,
     }
 
 
@@ -155,6 +186,12 @@ def main():
         local_rank = 0
     if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    # one process per GPU: fewer devices than ranks cannot work (RCCL refuses two ranks on one device) and must not
+    # hang in a collective — every rank sees the same count and leaves before any rendezvous
+    ndev = torch.cuda.device_count()
+    if world > ndev and not os.environ.get('CC_BENCH_ONE_DEVICE'):
+        raise SystemExit(f'bench.py rank {rank}: --gpus {world} needs {world} visible GPUs, this host shows {ndev} '
+                         f'(one-GPU rehearsal of the multi-rank path: CC_BENCH_ONE_DEVICE=1, gloo collective)')
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -176,10 +213,12 @@ def main():
     host_enc_t = torch.empty((hi - lo, args.latent), dtype=torch.float32, pin_memory=True)
     host_enc = host_enc_t.numpy()
 
+    host_ms = {}   # host-clock milliseconds of this rank per stage, summed over the timed steps (pipeline `timings`)
+
     def step():
         # encodings reach pinned host memory on a side stream while the kNN search runs
         return pipeline.encode_and_knn(enc, local, args.k, backend=backend, host_encodings=host_enc_t,
-                                       n_total=args.cells if world > 1 else None)
+                                       n_total=args.cells if world > 1 else None, timings=host_ms)
 
     def fence():
         torch.cuda.synchronize()
@@ -192,6 +231,7 @@ def main():
     _lib.profile_enable(not args.no_profile)
     _lib.profile_reset()
     fence()
+    host_ms.clear()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         res = step()
@@ -199,10 +239,22 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = _lib.profile_snapshot()
     _lib.profile_enable(False)
+    main_host_ms = {k: v / args.steps for k, v in host_ms.items()}
+    main_sample = host_enc.copy()   # the alt legs below reuse the pinned buffer
+    stages_by_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=backend.collective_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # per stage: slowest and fastest rank (kernel classes from the library's HIP events + the host-clock stages)
+        mine = {k: v['ms'] / args.steps for k, v in prof.items() if v['launches']}
+        mine.update({'host_' + k: v for k, v in main_host_ms.items()})
+        mine['host_step_ms'] = sum(main_host_ms.values())
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        keys = sorted(set().union(*[set(d) for d in everyone]))
+        stages_by_rank = {k: {'max': max(d.get(k, 0.0) for d in everyone), 'min': min(d.get(k, 0.0) for d in everyone),
+                              'argmax_rank': int(np.argmax([d.get(k, 0.0) for d in everyone]))} for k in keys}
 
     def timed_alt(alt_enc):
         """The same K steps with another encoder object; returns (seconds over all ranks, profile snapshot)."""
@@ -228,51 +280,75 @@ def main():
             secs = float(tt.item())
         return secs, snap
 
-    # Same workload once more with layers 1-2 on the fp16 matrix cores (hi+lo split operands,
-    # fp32-equivalent: tests/test_gpu_encoder_f16.py holds it to the same 1e-4 tolerance).
-    # Reported under "alt"; it never feeds `value`.
-    alt = alt_sparse = None
+    # The same workload once more per opt-in encoder mode; reported under "alt*", never `value`.  Each leg leaves the
+    # first rows of its encodings behind so that the CPU sample below puts an error figure on it as well.
+    alt = alt_f16 = alt_sparse = None
+    alt_samples = {}
+    keep_rows = min(args.cpu_sample_cells, hi - lo)
+
+    def gemm16_leg(dtype, products, note):
+        leg_enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321, batch_rows=args.batch_rows or None, dtype=dtype)
+        secs, snap = timed_alt(leg_enc)
+        a1 = snap['gemm_l1']
+        executed = products * a1['work'] / (a1['ms'] * 1e-3) / 1e12 if a1['ms'] > 0 else 0.0
+        leg = {'dtype': dtype, 'value': args.cells * args.steps / secs, 'unit': 'cells/s',
+               'ms_per_step': secs / args.steps * 1e3,
+               'layer1_algorithmic_tflops': executed / products, 'layer1_executed_fp16_tflops': executed,
+               'roofline': {'kernel': f'gemm16_kernel (layer 1, {products} fp16 product(s) per algorithmic product)',
+                            'bound': 'mfma', 'achieved': executed, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                            'frac': executed / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
+                            'avg_launch_ms': a1['ms'] / max(a1['launches'], 1),
+                            'flop_per_launch': products * a1['work'] / max(a1['launches'], 1)},
+               'fp32_fallback_passes': leg_enc.fp32_fallback_passes(),
+               'stages_rank0': {k: {'launches': v['launches'], 'ms_per_step': v['ms'] / args.steps}
+                                for k, v in snap.items() if v['launches']},
+               'note': note}
+        return leg, host_enc[:keep_rows].copy()
+
     if args.dtype == 'f32' and not args.sparse and not args.no_alt:
-        alt_enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321, batch_rows=args.batch_rows or None,
-                                dtype='f16x2')
-        alt_elapsed, alt_prof = timed_alt(alt_enc)
-        a1 = alt_prof['gemm_l1']
-        executed = 2 * a1['work'] / (a1['ms'] * 1e-3) / 1e12 if a1['ms'] > 0 else 0.0
-        alt = {'dtype': 'f16x2', 'value': args.cells * args.steps / alt_elapsed, 'unit': 'cells/s',
-               'ms_per_step': alt_elapsed / args.steps * 1e3,
-               'layer1_algorithmic_tflops': executed / 2, 'layer1_executed_fp16_tflops': executed,
-               'roofline': {'kernel': 'gemm16_kernel (layer 1, two fp16 products per algorithmic product)', 'bound': 'mfma',
-                            'achieved': executed, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                            'frac': executed / PEAK_F16_MFMA_TFLOPS, 'traffic': None},
-               'fp32_fallback_passes': alt_enc.fp32_fallback_passes(),
-               'note': 'encoder layers 1-2 as v_mfma_f32_32x32x16_f16 on W = W_hi + W_lo (and A = A_hi + A_lo for the '
-                       'sigmoid activations), fp32 accumulate; same 1e-4 parity bound as f32; not the headline'}
-        del alt_enc
+        alt, alt_samples['alt'] = gemm16_leg(
+            'f16x2', 2, 'encoder layers 1-2 as v_mfma_f32_16x16x32_f16 on W = W_hi + W_lo (and A = A_hi + A_lo for the sigmoid '
+                        'activations), fp32 accumulate; same 1e-4 parity bound as f32; not the headline')
+        alt_f16, alt_samples['alt_f16'] = gemm16_leg(
+            'f16', 1, 'the arithmetic BASELINE configs[4] names: operands of layers 1-2 rounded to fp16 once, fp32 accumulate '
+                      '(v_mfma_f32_16x16x32_f16); parity bound 1e-4 against the float64 evaluation of the rounded operands '
+                      '(tests/test_gpu_encoder_f16.py, test_gpu_configs.py), NOT against the fp32 encoder; not the headline')
         # ... and with the sparse first layer: exact fp32 FMAs over the non-zeros only (csrc/spmm.hip)
         sp_enc = cc.HipEncoder(args.latent, args.genes, args.arch, seed=4321, sparse=True)
         sp_elapsed, sp_prof = timed_alt(sp_enc)
+        alt_samples['alt_sparse'] = host_enc[:keep_rows].copy()
         s1 = sp_prof['spmm_l1']
         nz_tflops = s1['work'] / (s1['ms'] * 1e-3) / 1e12 if s1['ms'] > 0 else 0.0
+        # the binding resource is LDS read bandwidth: every non-zero costs each of its layer-1 column panels one
+        # ds_read_b128 wave instruction = 1 KiB (the 4 weights of that k-row per lane), i.e. 4 B of LDS per FMA
+        lds_tbs = nz_tflops / 2.0 * 4.0
         alt_sparse = {'dtype': 'f32', 'value': args.cells * args.steps / sp_elapsed, 'unit': 'cells/s',
                       'ms_per_step': sp_elapsed / args.steps * 1e3,
                       'roofline': {'kernel': 'spmm_bias_act_kernel<1> (layer 1 over the non-zeros, fp32 vector FMAs)',
-                                   'bound': 'valu', 'achieved': nz_tflops, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                                   'frac': nz_tflops / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
+                                   'bound': 'lds', 'achieved': lds_tbs, 'peak': PEAK_LDS_TBS, 'unit': 'TB/s',
+                                   'frac': lds_tbs / PEAK_LDS_TBS, 'traffic': None,
                                    'avg_launch_ms': s1['ms'] / max(s1['launches'], 1),
+                                   'lds_bytes_per_launch': s1['work'] / 2.0 * 4.0 / max(s1['launches'], 1),
                                    'flop_per_launch': s1['work'] / max(s1['launches'], 1),
+                                   'fp32_fma_tflops': nz_tflops, 'fp32_vector_peak_tflops': PEAK_F32_MFMA_TFLOPS,
+                                   'frac_of_vector_peak': nz_tflops / PEAK_F32_MFMA_TFLOPS,
                                    'dense_equivalent_tflops': (2.0 * (hi - lo) * args.genes * enc.layers[1].units * args.steps
-                                                               / (s1['ms'] * 1e-3) / 1e12) if s1['ms'] > 0 else None},
+                                                               / (s1['ms'] * 1e-3) / 1e12) if s1['ms'] > 0 else None,
+                                   'note': 'achieved = algorithmic LDS read bytes (1 KiB per non-zero and 256-column panel '
+                                           '= 4 B per FMA) / kernel time; peak = 256 B/clk/CU x 256 CUs x 2.4 GHz. A kernel '
+                                           'of this shape (one weight read per FMA) cannot exceed half the vector peak.'},
                       'stages_rank0': {k: {'launches': v['launches'], 'ms_per_step': v['ms'] / args.steps}
                                        for k, v in sp_prof.items() if v['launches']},
                       'note': 'sparse-aware first layer (SURVEY 8 f4): x @ K1 and the raw-input rows of K2 as CSR x dense '
                               'products over the ~5% non-zeros, fp32 FMA on the vector ALUs; no gather, no dense copy of '
-                              'the counts; same 1e-4 parity bound (tests/test_gpu_sparse.py); opt-in, not the headline'}
+                              'the counts; same 1e-4 parity bound (tests/test_gpu_sparse.py, test_gpu_configs.py at this '
+                              'size); opt-in, not the headline'}
         del sp_enc
 
     # Side numbers for the reference's actual call shapes (dense host input: BasicBiGan.encoding_prediction gets a
     # DataFrame, reference src/bigan_basic.py:28-30; keras predict batches of 32, src/__main__.py:44 batch_size 128).
     dense_host = None
-    if world == 1 and args.dense_host and args.dtype == 'f32':
+    if world == 1 and not args.no_dense_host and (args.dense_host or not args.no_alt) and args.dtype == 'f32' and not args.sparse:
         nd = min(16384, hi - lo)
         ld = (args.genes + 31) // 32 * 32
         dense_t = torch.empty((nd, ld), dtype=torch.float32, pin_memory=True)
@@ -313,8 +389,9 @@ def main():
     if rank == 0:
         traffic = None   # HBM-side bytes per launch, REPLAYED from the PMC passes committed under profiles/
         dominant = 'spmm_bias_act_kernel<1>' if args.sparse else 'gemm_bias_act_kernel<1>'
+        traffic_profile = next((f for f in TRAFFIC_PROFILES if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
         try:
-            kernels = json.load(open(os.path.join(ROOT, 'profiles', TRAFFIC_PROFILE)))['kernels']
+            kernels = json.load(open(os.path.join(ROOT, 'profiles', traffic_profile)))['kernels']
             pmc = next(v for k, v in kernels.items() if dominant in k)
             fetch = pmc['FETCH_SIZE']['mean_per_launch'] if isinstance(pmc['FETCH_SIZE'], dict) else pmc['FETCH_SIZE']
             write = pmc['WRITE_SIZE']['mean_per_launch'] if isinstance(pmc['WRITE_SIZE'], dict) else pmc['WRITE_SIZE']
@@ -346,14 +423,14 @@ def main():
                         'traffic': None if args.sparse else traffic,
                         'traffic_note': f'REPLAYED, not measured in this run: bytes per launch of the dominant kernel, '
                                         f'2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes of the same command '
-                                        f'(profiles/{TRAFFIC_PROFILE}); algorithmic minimum 1.45e9 for the dense kernel',
+                                        f'(profiles/{traffic_profile}); algorithmic minimum 1.45e9 for the dense kernel',
                         'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch}
         line = {
             'metric': baseline_metric(), 'value': args.cells * args.steps / elapsed,
             'unit': 'cells/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong',
             'vs_baseline': None, 'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[2]: synthetic {args.cells} cells x {args.genes} genes (5% dense '
+            'config': {'workload': f'{workload_name(args, world)}: synthetic {args.cells} cells x {args.genes} genes (5% dense '
                                    f'integer counts), {args.arch} encoder latent={args.latent} (random Glorot weights), '
                                    f'exact k={args.k} brute-force kNN',
                        'cells': args.cells, 'genes': args.genes, 'latent': args.latent, 'k': args.k,
@@ -362,8 +439,15 @@ def main():
             'roofline': roofline,
             'stages_rank0': stages,
         }
+        if stages_by_rank is not None:
+            line['stages_by_rank'] = stages_by_rank
+            line['allgather_ms'] = stages_by_rank.get('host_allgather_ms')
+        else:
+            line['host_stage_ms_rank0'] = main_host_ms
         if alt is not None:
             line['alt'] = alt
+        if alt_f16 is not None:
+            line['alt_f16'] = alt_f16
         if alt_sparse is not None:
             line['alt_sparse'] = alt_sparse
         if dense_host is not None:
@@ -395,7 +479,14 @@ def main():
             line['roofline_gather'] = {'kernel': 'csr_gather_kernel', 'bound': 'hbm', 'achieved': gbs,
                                        'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': gbs / PEAK_HBM_GBS}
         if world == 1 and not args.no_cpu_baseline:
-            line['cpu_baseline'] = cpu_baseline(args, enc, local, host_enc)
+            base = cpu_baseline(args, enc, local, main_sample, alt_samples)
+            for name, rel in base.pop('alt_max_rel').items():   # each leg carries its own error figure
+                leg = {'alt': alt, 'alt_f16': alt_f16, 'alt_sparse': alt_sparse}.get(name)
+                if leg is not None:
+                    leg['max_rel_vs_cpu_sample'] = rel
+                elif name == 'alt_f16_vs_f16_operand_oracle' and alt_f16 is not None:
+                    alt_f16['max_rel_vs_f16_operand_oracle_sample'] = rel
+            line['cpu_baseline'] = base
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

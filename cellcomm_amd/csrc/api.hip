@@ -16,6 +16,7 @@ static hipStream_t g_cur = nullptr;       // stream the launchers currently issu
 static hipEvent_t g_lead_done = nullptr;  // orders the overlapped pass pair of a short encode call behind its full passes
 static hipEvent_t g_slot_free[2] = {nullptr, nullptr}, g_slot_full[2] = {nullptr, nullptr};   // cc_encode_dense pipeline
 static int g_device = -1;
+static int g_generation = 0;
 
 void set_error(const char *fmt, ...) {
   char buf[1024];
@@ -27,6 +28,7 @@ void set_error(const char *fmt, ...) {
 }
 hipStream_t stream() { return g_cur ? g_cur : g_stream; }
 bool initialised() { return g_stream != nullptr; }
+int init_generation() { return g_generation; }
 
 // ---- profiling ---------------------------------------------------------------
 struct ProfRec { int klass; double work; hipEvent_t e0, e1; };
@@ -113,7 +115,7 @@ struct Encoder {
   int64_t tail_rows = 0;
   float *h2_all = nullptr, *h3_all = nullptr, *h4_all = nullptr;
   // sparse first layer (cc_encoder_set_sparse_input): x @ K1 and the raw-input rows of K2 as CSR x dense products
-  // on the vector ALUs; the whole call is one pass, so layer 1's output is kept for all rows too
+  // on the vector ALUs; passes of 8 x `batch` rows, h1_all / h2_all ... hold one pass of it
   bool low_latency = false;        // calls of <= 128 rows: layers 1-3 as split-K (gemm_small.hip)
   bool sparse = false;
   SpmmWeight S1, S2;
@@ -282,24 +284,36 @@ static int encoder_ensure_all_rows(Encoder *e, int64_t n, bool with_h1) {
 
 static int encoder_tail_cont(Encoder *e, const float *h2, int64_t M, float *h3, float *h4, float *out);
 
-// Sparse first layer: the whole range in one pass, no dense copy of the counts (reference graphs
-// src/bigan_cont.py:32-41, src/bigan_classify.py:31-39; see spmm.hip).
+// Sparse first layer: no dense copy of the counts (reference graphs src/bigan_cont.py:32-41,
+// src/bigan_classify.py:31-39; see spmm.hip).  The range runs in passes of 8 x the encoder's pass size (65536 rows by
+// default: 12 panels x 256 row blocks = 12 whole rounds of layer-1 workgroups), cut at absolute 256-row block
+// boundaries so that no workgroup's rows belong to two passes; the activations exist for one pass only.  A row's
+// result does not depend on the pass it falls into (its non-zeros are always added in column order).
 static int encode_csr_sparse(Encoder *e, Csr *c, int64_t row_start, int64_t n, float *dev_out) {
   int rc;
   e->ldx = pad32(e->G); e->ld1 = pad32(e->w0); e->ld2 = pad32(e->w1); e->ld3 = pad32(150);
-  if ((rc = encoder_ensure_all_rows(e, n, true))) return rc;
-  const double nnz_hint = c->n_rows ? (double)c->nnz / (double)c->n_rows * (double)n : 0.0;
-  if ((rc = launch_spmm(c->stream, row_start, n, e->S1, nullptr, 0, e->h1_all, e->ld1, ACT_SIGMOID, CC_PROF_SPMM_L1, nnz_hint))) return rc;
-  if (e->arch == CC_ARCH_CONT) {
-    // layer 2 = sigmoid(h1 @ K2[:w0] + b2  (dense MFMA, linear)  +  x @ K2[w0:]  (sparse, adds the dense part, activates))
-    if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, n, e->L2a, e->h2_all, e->ld2, ACT_LINEAR, CC_PROF_GEMM_L2))) return rc;
-    if ((rc = launch_spmm(c->stream, row_start, n, e->S2, e->h2_all, e->ld2, e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_SPMM_L2, nnz_hint))) return rc;
-    if ((rc = encoder_tail_cont(e, e->h2_all, n, e->h3_all, e->h4_all, dev_out))) return rc;
-  } else {
-    if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, n, e->L[1], e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
-    if ((rc = launch_gemm(e->h2_all, e->ld2, e->h1_all, e->ld1, n, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
-    if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, n, e->L[3], dev_out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
-    if ((rc = launch_row_softmax(dev_out, n, e->E, e->E))) return rc;
+  const int64_t P = round_up(e->batch, SPMM_ROWS) * 8;
+  if ((rc = encoder_ensure_all_rows(e, n < P ? n : P, true))) return rc;
+  const double nnz_per_row = c->n_rows ? (double)c->nnz / (double)c->n_rows : 0.0;
+  const int64_t end = row_start + n;
+  for (int64_t r0 = row_start; r0 < end;) {
+    const int64_t cut = r0 / SPMM_ROWS * SPMM_ROWS + P;
+    const int64_t r1 = cut < end ? cut : end, m = r1 - r0;
+    const double nnz_hint = nnz_per_row * (double)m;
+    float *out = dev_out + (r0 - row_start) * e->E;
+    if ((rc = launch_spmm(c->stream, r0, m, e->S1, nullptr, 0, e->h1_all, e->ld1, ACT_SIGMOID, CC_PROF_SPMM_L1, nnz_hint))) return rc;
+    if (e->arch == CC_ARCH_CONT) {
+      // layer 2 = sigmoid(h1 @ K2[:w0] + b2  (dense MFMA, linear)  +  x @ K2[w0:]  (sparse, adds the dense part, activates))
+      if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, m, e->L2a, e->h2_all, e->ld2, ACT_LINEAR, CC_PROF_GEMM_L2))) return rc;
+      if ((rc = launch_spmm(c->stream, r0, m, e->S2, e->h2_all, e->ld2, e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_SPMM_L2, nnz_hint))) return rc;
+      if ((rc = encoder_tail_cont(e, e->h2_all, m, e->h3_all, e->h4_all, out))) return rc;
+    } else {
+      if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, m, e->L[1], e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
+      if ((rc = launch_gemm(e->h2_all, e->ld2, e->h1_all, e->ld1, m, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
+      if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, m, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
+      if ((rc = launch_row_softmax(out, m, e->E, e->E))) return rc;
+    }
+    r0 = r1;
   }
   CC_HIP(hipStreamSynchronize(stream()));
   return CC_OK;
@@ -418,21 +432,32 @@ static int check_rows(const Csr *c, const int64_t *row_ids, int64_t row_start, i
 }
 
 static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t row_start, int64_t n,
-                          float *dev_out) {
+                          float *dev_out, bool nested = false) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
   CC_REQUIRE(c->G == e->G, "matrix has %d genes, encoder expects %d", c->G, e->G);
   int rc;
   if ((rc = check_rows(c, row_ids, row_start, n))) return rc;
   if (e->dirty && (rc = encoder_pack(e))) return rc;
-  e->fallback_passes = 0;
+  if (!nested) e->fallback_passes = 0;
   if (n == 0) return CC_OK;
   // contiguous rows of a matrix through the sparse first layer; sampled rows (minibatches) and degenerate widths
   // (int(G*0.1) == 0) keep the gather + dense path
-  if (e->sparse && e->dtype == CC_DTYPE_F32 && !row_ids && e->w0 > 0 && e->w1 > 0) {
+  if (!nested && e->sparse && e->dtype == CC_DTYPE_F32 && !row_ids && e->w0 > 0 && e->w1 > 0) {
     if (!c->stream.d_offs && !c->stream.unusable &&
         (rc = build_spmm_stream(c->indptr, c->indices, c->vals, c->n_rows, c->G, &c->stream)))
       return rc;
     if (!c->stream.unusable) return encode_csr_sparse(e, c, row_start, n, dev_out);
+  }
+  // very long calls: in chunks of 32 passes, so that the all-rows buffer of the once-per-call tail (6 KB per row at
+  // G = 30000) stays bounded; a row's result does not depend on the chunk or pass it falls into
+  if (!nested && n > 32 * e->batch) {
+    const int64_t chunk = 32 * e->batch;
+    for (int64_t off = 0; off < n; off += chunk) {
+      const int64_t m = n - off < chunk ? n - off : chunk;
+      if ((rc = encode_csr_dev(e, c, row_ids ? row_ids + off : nullptr, row_start + off, m, dev_out + off * e->E, true)))
+        return rc;
+    }
+    return CC_OK;
   }
   // Pass plan.  GEMM time is quantised in rounds of 768 resident tiles, so a short pass leaves most
   // CUs idle in its final round.  Calls of 2-4 passes (the per-rank shards at 4 and 8 GPUs) are cut
@@ -522,7 +547,7 @@ using namespace cc;
 
 extern "C" {
 
-int cc_version(void) { return 102; }   // 102: cc_shutdown, kNN workspace handles (cc_knn_create / cc_knn_search_dev), GPU-side CSR check
+int cc_version(void) { return 103; }   // 103: NULL handles / buffers refused, sparse passes, wrapped indptr checked end to end (102: cc_shutdown, kNN workspace handles)
 const char *cc_last_error(void) { return g_err.c_str(); }
 
 int cc_device_count(void) {
@@ -553,6 +578,7 @@ int cc_init(int device) {
   CC_HIP(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
   g_cur = nullptr;
   g_device = device;
+  ++g_generation;
   return CC_OK;
 }
 
@@ -580,6 +606,7 @@ int cc_shutdown(void) {
 
 int cc_device_name(char *buf, int buflen) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
+  CC_REQUIRE(buf != nullptr && buflen > 0, "buf is NULL or empty");
   hipDeviceProp_t prop;
   CC_HIP(hipGetDeviceProperties(&prop, g_device));
   snprintf(buf, (size_t)buflen, "%s (%s, %d CUs)", prop.name, prop.gcnArchName, prop.multiProcessorCount);
@@ -621,9 +648,16 @@ void cc_encoder_free(void *enc) {
   delete e;
 }
 
-int cc_encoder_num_weights(void *enc) { return (int)static_cast<Encoder *>(enc)->shapes.size(); }
+#define CC_HANDLE(h, what) CC_REQUIRE((h) != nullptr, what " handle is NULL")
+
+int cc_encoder_num_weights(void *enc) {
+  if (!enc) { set_error("encoder handle is NULL"); return -1; }
+  return (int)static_cast<Encoder *>(enc)->shapes.size();
+}
 
 int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols) {
+  CC_HANDLE(enc, "encoder");
+  CC_REQUIRE(rows && cols, "rows / cols is NULL");
   Encoder *e = static_cast<Encoder *>(enc);
   CC_REQUIRE(idx >= 0 && idx < (int)e->shapes.size(), "weight index %d out of range", idx);
   *rows = e->shapes[idx].rows;
@@ -632,12 +666,14 @@ int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols) {
 }
 
 int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols) {
+  CC_HANDLE(enc, "encoder");
   Encoder *e = static_cast<Encoder *>(enc);
   CC_REQUIRE(idx >= 0 && idx < (int)e->shapes.size(), "weight index %d out of range", idx);
   const WShape s = e->shapes[idx];
   CC_REQUIRE(rows == s.rows && cols == s.cols, "weight %d has shape (%lld,%lld), expected (%lld,%lld)", idx,
              (long long)rows, (long long)cols, (long long)s.rows, (long long)s.cols);
   const int64_t count = s.rows * (s.cols < 0 ? 1 : s.cols);
+  CC_REQUIRE(host != nullptr || count == 0, "weight %d: host pointer is NULL", idx);
   e->w[idx].assign(host, host + count);
   e->have[idx] = true;
   e->dirty = true;
@@ -645,6 +681,7 @@ int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, 
 }
 
 int cc_encoder_set_sparse_input(void *enc, int on) {
+  CC_HANDLE(enc, "encoder");
   Encoder *e = static_cast<Encoder *>(enc);
   CC_REQUIRE(!on || e->dtype == CC_DTYPE_F32, "the sparse first layer computes in fp32: create the encoder with CC_DTYPE_F32");
   if (e->sparse != (on != 0)) e->dirty = true;   // the panel-packed weights are made at the next pack
@@ -653,13 +690,18 @@ int cc_encoder_set_sparse_input(void *enc, int on) {
 }
 
 int cc_encoder_set_low_latency(void *enc, int on) {
+  CC_HANDLE(enc, "encoder");
   static_cast<Encoder *>(enc)->low_latency = on != 0;
   return CC_OK;
 }
 
-int64_t cc_encoder_fp32_fallback_passes(void *enc) { return static_cast<Encoder *>(enc)->fallback_passes; }
+int64_t cc_encoder_fp32_fallback_passes(void *enc) {
+  if (!enc) { set_error("encoder handle is NULL"); return -1; }
+  return static_cast<Encoder *>(enc)->fallback_passes;
+}
 
 int cc_encoder_set_batch(void *enc, int64_t batch_rows) {
+  CC_HANDLE(enc, "encoder");
   CC_REQUIRE(batch_rows >= 1, "batch_rows must be >= 1");
   static_cast<Encoder *>(enc)->batch = batch_rows;
   return CC_OK;
@@ -670,6 +712,7 @@ int cc_csr_upload(const int64_t *indptr, const int32_t *indices, const float *va
                   int64_t nnz, int G, void **csr) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
   CC_REQUIRE(csr && indptr && n_rows >= 0 && nnz >= 0 && G >= 1, "bad CSR arguments");
+  CC_REQUIRE(nnz == 0 || (indices && vals), "bad CSR arguments: indices / vals is NULL");
   CC_REQUIRE(indptr[0] == 0 && indptr[n_rows] == nnz, "indptr must start at 0 and end at nnz");
   Csr *c = new Csr();
   c->n_rows = n_rows; c->nnz = nnz; c->G = G; c->owned = true;
@@ -697,6 +740,7 @@ int cc_csr_wrap_device(const int64_t *dev_indptr, const int32_t *dev_indices, co
                        int64_t n_rows, int64_t nnz, int G, void **csr) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
   CC_REQUIRE(csr && dev_indptr && n_rows >= 0 && nnz >= 0 && G >= 1, "bad CSR arguments");
+  CC_REQUIRE(nnz == 0 || (dev_indices && dev_vals), "bad CSR arguments: indices / vals is NULL");
   Csr *c = new Csr();
   c->indptr = const_cast<int64_t *>(dev_indptr);
   c->indices = const_cast<int32_t *>(dev_indices);
@@ -724,9 +768,11 @@ void cc_csr_free(void *csr) {
 int cc_gather_dense(void *csr, const int64_t *row_ids, int64_t row_start, int64_t n, int64_t ld, void *out,
                     int out_is_device) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
+  CC_HANDLE(csr, "CSR");
   Csr *c = static_cast<Csr *>(csr);
   int rc;
   if ((rc = check_rows(c, row_ids, row_start, n))) return rc;
+  CC_REQUIRE(out != nullptr || n == 0, "out is NULL");
   CC_REQUIRE(ld >= c->G && ld % 4 == 0, "ld=%lld must be a multiple of 4 and >= G=%d", (long long)ld, c->G);
   if (n == 0) return CC_OK;
   DevPtr ids_buf, out_buf;   // released on every return path
@@ -750,10 +796,16 @@ int cc_gather_dense(void *csr, const int64_t *row_ids, int64_t row_start, int64_
 }
 
 int cc_encode_dev(void *enc, void *csr, const int64_t *row_ids, int64_t row_start, int64_t n, float *dev_out) {
+  CC_HANDLE(enc, "encoder");
+  CC_HANDLE(csr, "CSR");
+  CC_REQUIRE(dev_out != nullptr || n <= 0, "dev_out is NULL");
   return encode_csr_dev(static_cast<Encoder *>(enc), static_cast<Csr *>(csr), row_ids, row_start, n, dev_out);
 }
 
 int cc_encode(void *enc, void *csr, const int64_t *row_ids, int64_t row_start, int64_t n, float *host_out) {
+  CC_HANDLE(enc, "encoder");
+  CC_HANDLE(csr, "CSR");
+  CC_REQUIRE(host_out != nullptr || n <= 0, "host_out is NULL");
   Encoder *e = static_cast<Encoder *>(enc);
   if (n <= 0) return encode_csr_dev(e, static_cast<Csr *>(csr), row_ids, row_start, n, nullptr);
   if (int rc = e->out_buf.alloc(sizeof(float) * (size_t)(n * e->E))) return rc;
@@ -770,8 +822,10 @@ int cc_encode(void *enc, void *csr, const int64_t *row_ids, int64_t row_start, i
 // (120 KB per cell at G = 30000 against ~2 us of GPU time per cell), see DESIGN.md §6.
 int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
+  CC_HANDLE(enc, "encoder");
   Encoder *e = static_cast<Encoder *>(enc);
   CC_REQUIRE(n >= 0, "negative row count");
+  CC_REQUIRE((host_x != nullptr && host_out != nullptr) || n == 0, "host_x / host_out is NULL");
   int rc;
   if (e->dirty && (rc = encoder_pack(e))) return rc;
   e->fallback_passes = 0;
@@ -839,6 +893,7 @@ int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_se
               float *host_dist) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
   CC_REQUIRE(n_total > 0 && d > 0, "knn: empty input");
+  CC_REQUIRE(host_x != nullptr, "host_x is NULL");
   DevPtr x;
   CC_HIP(x.alloc(sizeof(float) * (size_t)(n_total * d)));
   CC_HIP(hipMemcpy(x.p, host_x, sizeof(float) * (size_t)(n_total * d), hipMemcpyHostToDevice));
@@ -858,6 +913,7 @@ int cc_profile_reset(void) {
 }
 int cc_profile_get(int klass, int64_t *launches, double *ms, double *work) {
   CC_REQUIRE(klass >= 0 && klass < CC_PROF_NUM, "profile class %d out of range", klass);
+  CC_REQUIRE(launches && ms && work, "output pointer is NULL");
   prof_drain();
   *launches = g_launches[klass];
   *ms = g_ms[klass];

@@ -8,6 +8,7 @@
 // 128-byte unique id that rank 0 makes (cc_comm_unique_id) and the host program distributes
 // (file, env, MPI, torch.distributed store ...).
 #include <dlfcn.h>
+#include <rccl/rccl.h>   // types and prototypes only: nothing here links against librccl, the entry points come from dlsym
 
 #include <cstdlib>
 
@@ -15,15 +16,20 @@
 
 namespace {
 
-constexpr int kUniqueIdBytes = 128;       // NCCL_UNIQUE_ID_BYTES
-struct UniqueId { char internal[kUniqueIdBytes]; };
-constexpr int kNcclFloat = 7;             // ncclFloat32
+// The C ABI (include/cellcomm_hip.h) promises a 128-byte id; the pointer types below are the header's own
+// prototypes, so a change of RCCL's signatures or enums is a compile error here instead of a wrong call at N > 1.
+constexpr int kUniqueIdBytes = 128;
+static_assert(sizeof(ncclUniqueId) == kUniqueIdBytes && NCCL_UNIQUE_ID_BYTES == kUniqueIdBytes,
+              "cc_comm_unique_id / cc_comm_init exchange a 128-byte id");
+using UniqueId = ncclUniqueId;
+constexpr ncclDataType_t kNcclFloat = ncclFloat32;
+static_assert(ncclSuccess == 0, "CC_RCCL treats 0 as success");
 
-using GetUniqueIdFn = int (*)(UniqueId *);
-using CommInitRankFn = int (*)(void **, int, UniqueId, int);   // the id travels by value
-using CommDestroyFn = int (*)(void *);
-using AllGatherFn = int (*)(const void *, void *, size_t, int, void *, hipStream_t);
-using ErrorStringFn = const char *(*)(int);
+using GetUniqueIdFn = decltype(&ncclGetUniqueId);
+using CommInitRankFn = decltype(&ncclCommInitRank);   // the id travels by value
+using CommDestroyFn = decltype(&ncclCommDestroy);
+using AllGatherFn = decltype(&ncclAllGather);
+using ErrorStringFn = decltype(&ncclGetErrorString);
 
 struct Rccl {
   void *handle = nullptr;
@@ -63,15 +69,15 @@ int load_rccl() {
 
 #define CC_RCCL(expr)                                                                         \
   do {                                                                                        \
-    const int _r = (expr);                                                                    \
-    if (_r != 0) {                                                                            \
+    const ncclResult_t _r = (expr);                                                           \
+    if (_r != ncclSuccess) {                                                                            \
       cc::set_error("%s failed: %s", #expr, g_rccl.error_string ? g_rccl.error_string(_r) : "?"); \
       return CC_EHIP;                                                                         \
     }                                                                                         \
   } while (0)
 
 struct Comm {
-  void *nccl = nullptr;
+  ncclComm_t nccl = nullptr;
   int nranks = 0, rank = 0;
   float *d_send = nullptr, *d_all = nullptr;   // grow-only staging for cc_knn_l2_sharded
   size_t send_cap = 0, all_cap = 0;
@@ -112,8 +118,8 @@ int cc_comm_init(int nranks, int rank, const void *unique_id_128_bytes, void **c
   Comm *c = new Comm();
   c->nranks = nranks;
   c->rank = rank;
-  const int r = g_rccl.comm_init_rank(&c->nccl, nranks, id, rank);
-  if (r != 0) {
+  const ncclResult_t r = g_rccl.comm_init_rank(&c->nccl, nranks, id, rank);
+  if (r != ncclSuccess) {
     cc::set_error("ncclCommInitRank failed: %s", g_rccl.error_string(r));
     delete c;
     return CC_EHIP;

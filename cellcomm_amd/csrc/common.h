@@ -16,6 +16,9 @@ namespace cc {
 void set_error(const char *fmt, ...);
 hipStream_t stream();
 bool initialised();
+// Counts successful cc_init calls that (re)created the library context: per-device one-time setup (kernel attributes)
+// is keyed on it, so it is redone after cc_shutdown + cc_init — possibly on another device.
+int init_generation();
 
 // Kernel-class timers (HIP events on the library stream).
 struct ProfScope {

@@ -135,7 +135,8 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_f16_kernel(
 }
 
 // ---- canonical-form check (replaces a serial host loop over every non-zero) -----------------------
-// err[0] = smallest offending row + 1 (0 = clean), err[1] = what was wrong there
+// *err = min over offending rows of ((row + 1) << 2 | code), all ones = clean; code 1: indptr (not monotone, outside
+// [0, nnz], not starting at 0 in row 0, not ending at nnz in the last row), 2: column outside [0, G), 3: column order
 __global__ __launch_bounds__(256) void csr_validate_kernel(const int64_t *__restrict__ indptr,
                                                            const int32_t *__restrict__ indices, int64_t n_rows,
                                                            int64_t nnz, int G, unsigned long long *__restrict__ err) {
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(256) void csr_validate_kernel(const int64_t *__rest
   if (row >= n_rows) return;
   const int64_t lo = indptr[row], hi = indptr[row + 1];
   int bad = 0;
-  if (lo > hi || lo < 0 || hi > nnz) {
+  if (lo > hi || lo < 0 || hi > nnz || (row == 0 && lo != 0) || (row == n_rows - 1 && hi != nnz)) {
     bad = 1;
   } else {
     for (int64_t p = lo + lane; p < hi; p += 64) {
@@ -171,7 +172,7 @@ int validate_csr(const int64_t *d_indptr, const int32_t *d_indices, int64_t n_ro
   if (h == ~0ull) return CC_OK;
   const long long row = (long long)(h >> 2) - 1;
   switch ((int)(h & 3)) {
-    case 1: CC_REQUIRE(false, "indptr not monotone inside [0, nnz] at row %lld", row);
+    case 1: CC_REQUIRE(false, "indptr not monotone from 0 to nnz at row %lld", row);
     case 2: CC_REQUIRE(false, "a column of row %lld is outside [0,%d)", row, G);
     default: CC_REQUIRE(false, "columns of row %lld not strictly increasing", row);
   }

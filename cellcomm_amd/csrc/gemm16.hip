@@ -346,13 +346,13 @@ int launch_gemm16(const GemmSeg16 *segs, int nsegs, int64_t M, const PackedWeigh
   const int64_t MT = ceil_div(M, H_TM);
   const int64_t nwg = MT * W.NT;
   CC_REQUIRE(nwg < (int64_t)2147483647, "gemm16: grid too large");
-  static bool attr_done = false;
-  if (!attr_done) {
+  static int attr_gen = -1;   // per library context: redone after cc_shutdown + cc_init (maybe another device)
+  if (attr_gen != init_generation()) {
     CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<1>::LDS));
     CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<1>::LDS));
     CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<2>::LDS));
     CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<2>::LDS));
-    attr_done = true;
+    attr_gen = init_generation();
   }
   ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
   const _Float16 *wp = static_cast<const _Float16 *>(W.d_w);

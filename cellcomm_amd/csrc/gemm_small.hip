@@ -256,9 +256,9 @@ __global__ __launch_bounds__(S_THREADS) void tail_small_fused_kernel(
   if (NT4 > 1) ts_tile(hA, w4b, bias4, 1, KT4, N4, hB, KT5 * SBK, nullptr, 0, 0, lane, wave);
   __syncthreads();
   ts_tile(hB, w5a, bias5, 0, KT5, N5, nullptr, 0, out + (int64_t)row0 * ldo, ldo, M - row0, lane, wave);
-  if (NT5 > 1) {
-    ts_load_w(W5, 1, KT5, w4a, lane, wave);
-    ts_tile(hB, w4a, bias5, 1, KT5, N5, nullptr, 0, out + (int64_t)row0 * ldo, ldo, M - row0, lane, wave);
+  for (int t = 1; t < NT5; ++t) {   // wide encodings (E > 128): the remaining column tiles of the last layer
+    ts_load_w(W5, t, KT5, w4a, lane, wave);
+    ts_tile(hB, w4a, bias5, t, KT5, N5, nullptr, 0, out + (int64_t)row0 * ldo, ldo, M - row0, lane, wave);
   }
 }
 

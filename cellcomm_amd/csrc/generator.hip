@@ -148,9 +148,14 @@ void cc_generator_free(void *gen) {
   delete g;
 }
 
-int cc_generator_num_weights(void *gen) { return (int)static_cast<Generator *>(gen)->shapes.size(); }
+int cc_generator_num_weights(void *gen) {
+  if (!gen) { set_error("generator handle is NULL"); return -1; }
+  return (int)static_cast<Generator *>(gen)->shapes.size();
+}
 
 int cc_generator_weight_shape(void *gen, int idx, int64_t *rows, int64_t *cols) {
+  CC_REQUIRE(gen != nullptr, "generator handle is NULL");
+  CC_REQUIRE(rows && cols, "rows / cols is NULL");
   Generator *g = static_cast<Generator *>(gen);
   CC_REQUIRE(idx >= 0 && idx < (int)g->shapes.size(), "weight index %d out of range", idx);
   *rows = g->shapes[idx].rows;
@@ -159,11 +164,13 @@ int cc_generator_weight_shape(void *gen, int idx, int64_t *rows, int64_t *cols) 
 }
 
 int cc_generator_set_weights(void *gen, int idx, const float *host, int64_t rows, int64_t cols) {
+  CC_REQUIRE(gen != nullptr, "generator handle is NULL");
   Generator *g = static_cast<Generator *>(gen);
   CC_REQUIRE(idx >= 0 && idx < (int)g->shapes.size(), "weight index %d out of range", idx);
   const GShape s = g->shapes[idx];
   CC_REQUIRE(rows == s.rows && cols == s.cols, "weight %d has shape (%lld,%lld), expected (%lld,%lld)", idx,
              (long long)rows, (long long)cols, (long long)s.rows, (long long)s.cols);
+  CC_REQUIRE(host != nullptr || s.rows * (s.cols < 0 ? 1 : s.cols) == 0, "weight %d: host pointer is NULL", idx);
   g->w[idx].assign(host, host + s.rows * (s.cols < 0 ? 1 : s.cols));
   g->have[idx] = true;
   g->dirty = true;
@@ -172,8 +179,10 @@ int cc_generator_set_weights(void *gen, int idx, const float *host, int64_t rows
 
 int cc_generate_dense(void *gen, const float *host_in, int64_t n, float *host_out) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
+  CC_REQUIRE(gen != nullptr, "generator handle is NULL");
   Generator *g = static_cast<Generator *>(gen);
   CC_REQUIRE(n >= 0, "negative row count");
+  CC_REQUIRE((host_in != nullptr && host_out != nullptr) || n == 0, "host_in / host_out is NULL");
   int rc;
   if (g->dirty && (rc = generator_pack(g))) return rc;
   if (n == 0) return CC_OK;

@@ -1755,11 +1755,9 @@ KnnWorkspace *knn_default_ws() {
   if (!g_default_ws) g_default_ws = new KnnWorkspace();
   return g_default_ws;
 }
+// cc_shutdown: the device scratch goes, the options set through cc_knn_set_option(NULL, ..) stay
 void knn_default_ws_release() {
-  if (!g_default_ws) return;
-  g_default_ws->release();
-  delete g_default_ws;
-  g_default_ws = nullptr;
+  if (g_default_ws) g_default_ws->release();
 }
 
 struct SelectArgs {
@@ -1910,6 +1908,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
              "Expected n_neighbors <= n_samples_fit, but n_neighbors = %d, n_samples_fit = %lld", k,
              (long long)(N - (include_self ? 0 : 1)));
   if (n_q == 0) return CC_OK;
+  CC_REQUIRE(d_x && h_idx && h_dist, "knn: NULL %s", !d_x ? "points" : (!h_idx ? "index output" : "distance output"));
 
   static const int ng_opts[] = {1, 2, 3, 5, 9, 17};
   int NG = 0;

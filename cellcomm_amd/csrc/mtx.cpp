@@ -201,6 +201,7 @@ int cc_mtx_load(const char *path, void **handle) {
 
 int cc_mtx_shape(void *handle, int64_t *n_rows, int64_t *n_genes, int64_t *nnz) {
   CC_REQUIRE(handle, "cc_mtx_shape: NULL handle");
+  CC_REQUIRE(n_rows && n_genes && nnz, "cc_mtx_shape: NULL output pointer");
   const Mtx *m = static_cast<const Mtx *>(handle);
   *n_rows = (int64_t)m->barcodes.size();
   *n_genes = (int64_t)m->genes.size();
@@ -210,6 +211,7 @@ int cc_mtx_shape(void *handle, int64_t *n_rows, int64_t *n_genes, int64_t *nnz) 
 
 int cc_mtx_export(void *handle, int64_t *indptr, int32_t *indices, float *vals, int64_t *barcodes, int64_t *genes) {
   CC_REQUIRE(handle, "cc_mtx_export: NULL handle");
+  CC_REQUIRE(indptr && indices && vals && barcodes && genes, "cc_mtx_export: NULL output pointer");
   const Mtx *m = static_cast<const Mtx *>(handle);
   memcpy(indptr, m->indptr.data(), sizeof(int64_t) * m->indptr.size());
   if (!m->indices.empty()) {

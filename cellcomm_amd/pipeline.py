@@ -92,7 +92,7 @@ def encode_and_knn_native(encoder, local_matrix, k, comm, n_total, include_self=
 
 
 def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, group=None, host_encodings=None,
-                   n_total=None):
+                   n_total=None, timings=None):
     """Run the hot path on this rank's block of cells.
 
     `local_matrix` holds the rows of this rank (block `shard_bounds(n_total, world,
@@ -105,7 +105,16 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
     rank's encodings; the device-to-host copy runs on a side stream underneath the kNN search.
     `n_total` (optional): total number of cells when every rank holds block `shard_bounds(n_total, world, rank)`;
     saves the small collective that otherwise exchanges the block sizes each call.
+    `timings` (optional dict): host-clock milliseconds of this rank are ADDED to its keys `encode_ms`, `allgather_ms`
+    (from "my encodings are complete" to "everybody's are here": the collective plus the wait for the slowest rank)
+    and `knn_ms` — how a bad scaling curve is read (bench.py `stages_by_rank`).
     """
+    import time
+    clock = time.perf_counter
+
+    def tick(key, t_start):
+        if timings is not None:
+            timings[key] = timings.get(key, 0.0) + (clock() - t_start) * 1e3
     backend = backend or HipBackend()
     torch = backend.torch
     dist = torch.distributed
@@ -115,9 +124,13 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
 
     if not distributed:
         enc_all = backend.alloc(n_local, width)
+        t0 = clock()
         backend.encode_into(encoder, local_matrix, enc_all)
+        tick('encode_ms', t0)
         done = backend.copy_out(enc_all, host_encodings) if host_encodings is not None else None
+        t0 = clock()
         idx, dst = backend.knn(enc_all, n_local, 0, n_local, k, include_self)
+        tick('knn_ms', t0)
         if done is not None:
             done()
         return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=0, n_total=n_local)
@@ -142,22 +155,31 @@ def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, g
     enc_local = backend.alloc(per, width)
     if n_local < per:
         enc_local[n_local:].zero_()
+    t0 = clock()
     backend.encode_into(encoder, local_matrix, enc_local)
+    tick('encode_ms', t0)
     done = backend.copy_out(enc_local[:n_local], host_encodings) if host_encodings is not None else None
     gathered = backend.alloc(world * per, width)
     if backend.device == 'cuda':
         torch.cuda.synchronize()                # encoder ran on the library's stream
+    t0 = clock()
     if cdev == backend.device:
         dist.all_gather_into_tensor(gathered, enc_local, group=group)  # the one collective
     else:
         staged = torch.empty((world * per, width), dtype=torch.float32)
         dist.all_gather_into_tensor(staged, enc_local.cpu(), group=group)
         gathered.copy_(staged)
+    if timings is not None:
+        if backend.device == 'cuda':
+            torch.cuda.synchronize()            # (the search below starts with the same synchronisation)
+        tick('allgather_ms', t0)
     if all(int(c) == per for c in counts[:-1]):
         enc_all = gathered[:n_total]            # blocks are already back to back
     else:
         enc_all = torch.cat([gathered[r * per:r * per + int(counts[r])] for r in range(world)]).contiguous()
+    t0 = clock()
     idx, dst = backend.knn(enc_all, n_total, q_begin, n_local, k, include_self)
+    tick('knn_ms', t0)
     if done is not None:
         done()
     return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=q_begin, n_total=n_total)

@@ -10,6 +10,7 @@
 * optional additive fields ``nn`` / ``nd`` carry the kNN graph; cellan ignores
   unknown fields (reference cellan/backend/apiRouter.js:17-25).
 """
+import os
 import pickle
 from collections import defaultdict
 from datetime import datetime
@@ -129,6 +130,32 @@ def legacy_encs_document(iteration, encodings, barcodes):
         'ys': coords[:, 1].tolist(),
         'zs': coords[:, 2].tolist(),
     }
+
+
+def legacy_iteration_id(enc_file_name):
+    """Iteration id of an `.enc` file name as reference import_encodings.py:68 derives it:
+    `enc_file.rstrip('.enc')` — which strips trailing CHARACTERS out of {'.', 'e', 'n', 'c'}, not the suffix:
+    '5009.enc' -> '5009', but '100e.enc' -> '100' and 'dec.enc' -> 'd'."""
+    return enc_file_name.rstrip('.enc')
+
+
+def legacy_import_directory(encodings_dir, barcodes, collection=None, listdir=os.listdir):
+    """The legacy importer's main loop (reference import_encodings.py:66-77): one `encs` document per entry of
+    `logs/<run>/encodings`, in directory-listing order, `_id` = `legacy_iteration_id(name)`, coordinates read
+    from `<_id>.enc` — as the reference's `load_coords(iteration)` does, so a name the id rule mangles
+    ('100e.enc') loads '100.enc' (or raises FileNotFoundError when that does not exist).  `barcodes`: list of
+    names or the path of a barcodes.tsv.  Documents are returned and, when `collection` is given, passed to its
+    `insert_one` one by one (a pymongo collection or `recorder.MemoryDatabase()[...]`)."""
+    if isinstance(barcodes, (str, os.PathLike)):
+        barcodes = load_barcodes(barcodes)
+    docs = []
+    for enc_file in listdir(encodings_dir):
+        iteration = legacy_iteration_id(enc_file)
+        doc = legacy_encs_document(iteration, read_enc_file(os.path.join(encodings_dir, f'{iteration}.enc')), barcodes)
+        if collection is not None:
+            collection.insert_one(doc)
+        docs.append(doc)
+    return docs
 
 
 def write_enc_file(path, encodings):

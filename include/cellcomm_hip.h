@@ -16,7 +16,8 @@
  *   - `dev` pointers are HIP device pointers in the current process
  *     (e.g. torch.Tensor.data_ptr()); whatever produced their contents on another
  *     stream must have completed before the call (the library only orders its own work).
- *   - handles are opaque; free them with the matching *_free.
+ *   - handles are opaque; free them with the matching *_free.  A NULL handle or a NULL caller buffer is
+ *     refused with CC_EINVAL (the *_num_weights / *_fallback_passes counters return -1), *_free(NULL) is a no-op.
  *   - ONE device and ONE host thread at a time per process: cc_init binds the library to a
  *     device and owns its two HIP streams; every call returns synchronised; calls are not
  *     re-entrant (the reference's callers are single-threaded Python,
@@ -80,14 +81,21 @@ int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols);
  * BatchNormalization contributes gamma, beta, moving_mean, moving_variance).
  * reference src/bigan_cont.py:31-41, src/bigan_classify.py:29-40. */
 int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols);
-/* Rows processed per pass through the layer stack (default 8192 for CC_DTYPE_F32, 32768 for the fp16 dtypes). */
+/* Rows processed per pass through the layer stack (default 8192 for CC_DTYPE_F32, 32768 for the fp16 dtypes).
+ * The sparse first layer runs passes of 8 x this many rows (rounded up to whole 256-row blocks; default 65536),
+ * calls of more than 32 passes are processed in chunks of 32: device memory per call is bounded by the pass size,
+ * and a row's result depends neither on the pass nor on the call it falls into. */
 int cc_encoder_set_batch(void *enc, int64_t batch_rows);
 /* Sparse first layer (CC_DTYPE_F32 encoders only, default off).  When on, cc_encode /
  * cc_encode_dev of a CONTIGUOUS row range (row_ids == NULL) never densify the counts: x @ K1 and the raw-input
  * rows of K2 (reference src/bigan_cont.py:32-35, src/bigan_classify.py:31) run as CSR x dense products in fp32 on
  * the vector ALUs over the non-zeros only; the hidden-activation rows of K2 and the later layers stay on the fp32
  * matrix cores.  Same arithmetic type and tolerance as the dense path (summation order differs); sampled rows
- * and dense host input keep the gather + dense GEMM path. */
+ * and dense host input keep the gather + dense GEMM path.
+ * The first sparse call on a CSR handle builds that matrix's non-zero stream ON THE HANDLE: a re-ordered copy of
+ * the indices AND values (8 bytes per non-zero more device memory, ~62 ms per 100k cells once), kept until
+ * cc_csr_free.  It is a snapshot: see cc_csr_wrap_device.  Matrices the stream cannot hold (more than ~2.1e9
+ * non-zeros, more than ~154k genes) silently keep the gather + dense path. */
 int cc_encoder_set_sparse_input(void *enc, int on);
 /* Low-latency form for small calls (default off).  The reference calls predict on batches of 32 (keras default,
  * reference src/bigan_basic.py:30) and minibatches of 128 (src/__main__.py:44): with one row tile the two big
@@ -124,7 +132,10 @@ int cc_generate_dense(void *gen, const float *host_in, int64_t n, float *host_ou
 int cc_csr_upload(const int64_t *indptr, const int32_t *indices, const float *vals,
                   int64_t n_rows, int64_t nnz, int G, void **csr);
 /* Adopt device-resident CSR arrays (not copied, not freed by cc_csr_free); the same canonical
- * form is checked (indptr monotone from 0 to nnz, columns strictly increasing per row, < G). */
+ * form is checked (indptr monotone from 0 to nnz, columns strictly increasing per row, < G).
+ * The arrays are treated as IMMUTABLE for the life of the handle: the chunk index built here and the sparse
+ * first layer's stream (cc_encoder_set_sparse_input) are derived once and never refreshed, so a matrix whose
+ * values or structure change in place needs a new handle (free + wrap again). */
 int cc_csr_wrap_device(const int64_t *dev_indptr, const int32_t *dev_indices, const float *dev_vals,
                        int64_t n_rows, int64_t nnz, int G, void **csr);
 void cc_csr_free(void *csr);
@@ -169,7 +180,8 @@ void cc_mtx_free(void *mtx);
  * include_self = 0 drops candidate j == query index.  idx holds GLOBAL row
  * indices (int32).  Requires k <= n_total - (include_self ? 0 : 1); supported 1 <= k <= 128,
  * 1 <= d <= 132, n_total < 2^31.  cc_knn_l2 / cc_knn_l2_dev / cc_knn_l2_sharded use the library's
- * default workspace (grow-only scratch, released by cc_shutdown). */
+ * default workspace (grow-only scratch, released by cc_shutdown; options set on it with
+ * cc_knn_set_option(NULL, ..) outlive a shutdown). */
 int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_self,
               int32_t *host_idx, float *host_dist);
 int cc_knn_l2_dev(const float *dev_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q,

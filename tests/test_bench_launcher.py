@@ -91,6 +91,41 @@ def test_launcher_parent_does_not_import_torch():
     assert json.loads(proc.stdout.strip())['n_gpus'] == 2
 
 
+def test_workload_is_named_after_the_baseline_config_the_arguments_match():
+    """config.workload must not claim configs[2] for other shapes."""
+    import types
+    bench = load_bench()
+    mk = lambda **kw: types.SimpleNamespace(**dict(dict(cells=100000, genes=30000, latent=64, k=15, arch='cont', dtype='f32'), **kw))
+    assert bench.workload_name(mk(), 1) == 'BASELINE configs[2]'
+    assert bench.workload_name(mk(dtype='f16'), 4) == 'BASELINE configs[2]'
+    assert bench.workload_name(mk(cells=10000, genes=20000, latent=32), 1).startswith('BASELINE configs[1]')
+    assert bench.workload_name(mk(cells=1000000), 8) == 'BASELINE configs[3]'
+    assert bench.workload_name(mk(cells=500000, genes=33000, k=50, dtype='f16'), 8) == 'BASELINE configs[4]'
+    assert bench.workload_name(mk(cells=62500, genes=33000, k=50, dtype='f16'), 1).startswith('custom')
+    assert bench.workload_name(mk(cells=125000), 1).startswith('custom')
+    assert bench.workload_name(mk(cells=4242), 1) == 'custom'
+    assert bench.workload_name(mk(arch='cls'), 1) == 'custom'
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_without_two_devices_fails_fast(hip):
+    """`bench.py --gpus 2` on a host with ONE GPU (no rehearsal flag): every worker leaves with a one-line reason before
+    any collective, the launcher reports the failure — no hang, no re-exec.  (On a host with >= 2 GPUs the run is
+    simply valid and this test has nothing to check.)"""
+    import time
+    if hip.cc_device_count() >= 2:
+        pytest.skip('needs a one-GPU host')
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'CC_BENCH_ONE_DEVICE')}
+    t0 = time.time()
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                           '--cells', '2000', '--genes', '2000', '--latent', '8', '--no-cpu-baseline', '--no-alt'],
+                          capture_output=True, text=True, env=env, timeout=120)
+    assert proc.returncode != 0
+    assert time.time() - t0 < 120
+    assert 'needs 2 visible GPUs' in proc.stderr, proc.stderr[-3000:]
+    assert not [ln for ln in proc.stdout.splitlines() if ln.startswith('{')]
+
+
 @pytest.mark.gpu
 def test_bench_gpus_2_self_launch_on_one_device(hip):
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
@@ -103,4 +138,8 @@ def test_bench_gpus_2_self_launch_on_one_device(hip):
     assert len(lines) == 1, proc.stdout
     res = json.loads(lines[0])
     assert res['n_gpus'] == 2 and res['steps'] == 2 and res['value'] > 0
-    assert res['config']['cells'] == 6000
+    assert res['config']['cells'] == 6000 and res['config']['workload'].startswith('custom')
+    by_rank = res['stages_by_rank']                              # slowest / fastest rank per stage, for reading a bad curve
+    assert {'gather', 'gemm_l1', 'host_encode_ms', 'host_allgather_ms', 'host_knn_ms'} <= set(by_rank)
+    assert all(v['max'] >= v['min'] >= 0 and 0 <= v['argmax_rank'] < 2 for v in by_rank.values())
+    assert res['allgather_ms'] == by_rank['host_allgather_ms']

@@ -220,3 +220,97 @@ def test_init_is_idempotent_and_shutdown_releases_the_context(hip):
     assert np.array_equal(enc.predict(m), before)            # handles made before the shutdown keep working
     idx, _ = cc.knn_graph(before, 3)
     assert idx.shape == (300, 3)
+
+
+def test_null_handles_and_buffers_are_refused(hip):
+    """Every entry point that dereferences a handle or a caller buffer checks it first."""
+    lib = _lib.lib()
+    g, e = 400, 4
+    m = synth.synth_csr(50, g, seed=1)
+    enc = cc.HipEncoder(e, g, 'cont', seed=1)
+    out = np.empty((4, e), dtype=np.float32)
+    dense = np.zeros((4, g), dtype=np.float32)
+    r, c = ctypes.c_int64(), ctypes.c_int64()
+    calls = [
+        (lib.cc_encode, (None, m.device_handle(), None, 0, 4, out.ctypes.data), 'encoder handle is NULL'),
+        (lib.cc_encode, (enc._h, None, None, 0, 4, out.ctypes.data), 'CSR handle is NULL'),
+        (lib.cc_encode, (enc._h, m.device_handle(), None, 0, 4, None), 'host_out is NULL'),
+        (lib.cc_encode_dev, (enc._h, m.device_handle(), None, 0, 4, None), 'dev_out is NULL'),
+        (lib.cc_encode_dense, (None, dense.ctypes.data, 4, out.ctypes.data), 'encoder handle is NULL'),
+        (lib.cc_encode_dense, (enc._h, None, 4, out.ctypes.data), 'is NULL'),
+        (lib.cc_gather_dense, (None, None, 0, 4, g, dense.ctypes.data, 0), 'CSR handle is NULL'),
+        (lib.cc_gather_dense, (m.device_handle(), None, 0, 4, g, None, 0), 'out is NULL'),
+        (lib.cc_encoder_weight_shape, (None, 0, ctypes.byref(r), ctypes.byref(c)), 'encoder handle is NULL'),
+        (lib.cc_encoder_set_weights, (None, 0, dense.ctypes.data, 1, 1), 'encoder handle is NULL'),
+        (lib.cc_encoder_set_low_latency, (None, 1), 'encoder handle is NULL'),
+        (lib.cc_encoder_set_sparse_input, (None, 1), 'encoder handle is NULL'),
+        (lib.cc_encoder_set_batch, (None, 64), 'encoder handle is NULL'),
+        (lib.cc_generator_weight_shape, (None, 0, ctypes.byref(r), ctypes.byref(c)), 'generator handle is NULL'),
+        (lib.cc_generate_dense, (None, dense.ctypes.data, 4, dense.ctypes.data), 'generator handle is NULL'),
+        (lib.cc_mtx_shape, (None, ctypes.byref(r), ctypes.byref(c), ctypes.byref(c)), 'NULL handle'),
+        (lib.cc_knn_l2, (None, 10, 8, 3, 0, out.ctypes.data, out.ctypes.data), 'host_x is NULL'),
+        (lib.cc_device_name, (None, 0), 'buf is NULL'),
+    ]
+    for fn, args, text in calls:
+        assert fn(*args) == 1, fn.__name__
+        assert text in lib.cc_last_error().decode(), (fn.__name__, lib.cc_last_error().decode())
+    assert lib.cc_encoder_num_weights(None) == -1 and lib.cc_generator_num_weights(None) == -1
+    assert lib.cc_encoder_fp32_fallback_passes(None) == -1
+    lib.cc_encoder_free(None); lib.cc_csr_free(None); lib.cc_knn_free(None); lib.cc_generator_free(None)   # no-ops
+    assert enc.predict(m).shape == (50, e)
+
+
+def test_wrapped_indptr_must_run_from_zero_to_nnz(hip):
+    """cc_csr_wrap_device checked monotone rows but not that indptr starts at 0 and ends at nnz."""
+    lib = _lib.lib()
+    m = synth.synth_csr(40, 64, seed=3)
+    nnz = int(m.indptr[-1])
+    d_idx, d_val = torch.from_numpy(m.indices).cuda(), torch.from_numpy(m.values).cuda()
+    h = ctypes.c_void_p()
+    shifted = m.indptr.copy(); shifted[0] = 1
+    d_ptr = torch.from_numpy(shifted).cuda()
+    assert lib.cc_csr_wrap_device(d_ptr.data_ptr(), d_idx.data_ptr(), d_val.data_ptr(), 40, nnz, 64, ctypes.byref(h)) == 1
+    assert 'indptr not monotone from 0 to nnz at row 0' in lib.cc_last_error().decode()
+    d_ptr = torch.from_numpy(m.indptr).cuda()
+    assert lib.cc_csr_wrap_device(d_ptr.data_ptr(), d_idx.data_ptr(), d_val.data_ptr(), 40, nnz + 3, 64, ctypes.byref(h)) == 1
+    assert 'row 39' in lib.cc_last_error().decode()
+    assert lib.cc_csr_wrap_device(d_ptr.data_ptr(), d_idx.data_ptr(), d_val.data_ptr(), 40, nnz, 64, ctypes.byref(h)) == 0
+    lib.cc_csr_free(h)
+
+
+def test_shutdown_then_init_reruns_the_per_context_kernel_setup(hip):
+    """The 160 KiB dynamic-LDS attribute of the sparse and fp16 kernels is per library context: a
+    process that has used them, shut down and initialised again runs them again; options set on the default kNN
+    workspace survive the shutdown."""
+    lib = _lib.lib()
+    g, e = 1200, 8
+    m = synth.synth_csr(600, g, seed=5)
+    ws = eo.glorot_weights('cont', e, g, seed=6, randomize_bn=True, bias_scale=0.05)
+    truth = eo.forward('cont', ws, m.to_dense())
+
+    def run_all():
+        outs = []
+        for kw in (dict(sparse=True), dict(dtype='f16x2'), dict(dtype='f16')):
+            enc = cc.HipEncoder(e, g, 'cont', **kw)
+            enc.set_weights(ws)
+            outs.append(enc.predict(m))
+            del enc
+        return outs
+
+    first = run_all()
+    assert max_rel(first[0], truth) <= RTOL and max_rel(first[1], truth) <= RTOL
+    _lib.check(lib.cc_knn_set_option(None, 0, 1))            # CC_KNN_OPT_FORCE_FALLBACK on the default workspace
+    m._device = None                                         # the matrix handle is freed before the shutdown
+    import gc
+    gc.collect()
+    _lib.shutdown()
+    _lib.ensure_init(0)
+    again = run_all()
+    for a, b in zip(first, again):
+        assert np.array_equal(a, b)
+    x = np.random.default_rng(2).random((500, 8), dtype=np.float32)
+    try:
+        cc.knn_graph(x, 3)
+        assert lib.cc_knn_last_fallback_count() == 500       # the option outlived the shutdown
+    finally:
+        _lib.check(lib.cc_knn_set_option(None, 0, 0))

@@ -16,6 +16,14 @@ def max_rel(got, truth):
     return float(np.max(np.abs(got.astype(np.float64) - truth) / np.abs(truth)))
 
 
+def encode_range(enc, m, lo, hi):
+    """Rows [lo, hi) of a matrix in storage order (a contiguous range: the sparse first layer's route)."""
+    import torch
+    out = torch.empty((max(hi - lo, 1), enc.encoding_size), dtype=torch.float32, device='cuda')
+    enc.predict_to_device(m, out.data_ptr(), lo, hi - lo)
+    return out.cpu().numpy()[:hi - lo]
+
+
 def test_config2_encode_only_10k_x_20k_latent32(hip):
     # configs[1]: synthetic 10k cells x 20k genes, latent 32, encode only
     m, (indptr, indices, values) = synth.synth_csr_device(10000, 20000, seed=7)
@@ -29,20 +37,29 @@ def test_config2_encode_only_10k_x_20k_latent32(hip):
     assert np.array_equal(enc.predict(host.take(rows)), out[rows])      # row results are batch independent
 
 
-def test_config3_headline_size_properties(hip, oracle_built):
-    # configs[2], the bench workload at full size (100k cells x 30k genes, latent 64, k = 15): oracle on seeded
-    # samples plus properties that do not need it — idempotence, independence of a row's encoding from the rows
-    # around it, sortedness / self-exclusion / symmetry of the neighbour lists, f16x2 within tolerance of fp32.
-    n, g, e, k = 100000, 30000, 64, 15
+@pytest.fixture(scope='module')
+def c3(hip):
+    """configs[2] at full size, shared by the tests below: the matrix on the device and on the host, the dense fp32
+    encodings of all rows, 48 sampled rows with their float64 oracle truth."""
+    n, g, e = 100000, 30000, 64
     m, (indptr, indices, values) = synth.synth_csr_device(n, g, seed=1234)
     enc = cc.HipEncoder(e, g, 'cont', seed=4321)
     out = enc.predict(m)
+    host = cc.CellMatrix(indptr.cpu().numpy(), indices.cpu().numpy(), values.cpu().numpy(), g)
+    rows = np.random.default_rng(3).choice(n, 48, replace=False)
+    truth = eo.forward('cont', enc.get_weights(), host.take(rows).to_dense())
+    yield dict(n=n, g=g, e=e, m=m, keep=(indptr, indices, values), enc=enc, out=out, host=host, rows=rows, truth=truth)
+
+
+def test_config3_headline_size_properties(hip, oracle_built, c3):
+    # configs[2], the bench workload at full size (100k cells x 30k genes, latent 64, k = 15): oracle on seeded
+    # samples plus properties that do not need it — idempotence, independence of a row's encoding from the rows
+    # around it, sortedness / self-exclusion / symmetry of the neighbour lists, f16x2 within tolerance of fp32.
+    n, g, e, k = c3['n'], c3['g'], c3['e'], 15
+    m, enc, out, host, rows, truth = c3['m'], c3['enc'], c3['out'], c3['host'], c3['rows'], c3['truth']
+    rng = np.random.default_rng(3)
     assert out.shape == (n, e) and np.all(np.isfinite(out)) and np.all(out > 0) and np.all(out < 1)
     assert np.array_equal(enc.predict(m), out)                                    # idempotent, bit for bit
-    host = cc.CellMatrix(indptr.cpu().numpy(), indices.cpu().numpy(), values.cpu().numpy(), g)
-    rng = np.random.default_rng(3)
-    rows = rng.choice(n, 48, replace=False)
-    truth = eo.forward('cont', enc.get_weights(), host.take(rows).to_dense())
     assert max_rel(out[rows], truth) <= 1e-4
     block = host.take(np.arange(36990, 42010))                                    # straddles pass boundaries of the full run
     assert np.array_equal(enc.predict(block), out[36990:42010])
@@ -63,6 +80,43 @@ def test_config3_headline_size_properties(hip, oracle_built):
     has = back.any(axis=1)
     assert has.mean() > 0.3
     assert np.array_equal(dist[j][back][:], dist[has, 0])
+
+
+def test_config3_sparse_first_layer_at_the_size_the_bench_times_it(hip, c3):
+    # configs[2] through the sparse first layer (bench `alt_sparse`: 100k rows = 391 row blocks x 12 panels, stream
+    # offsets near 1.5e8, two 65536-row passes): sampled rows against the float64 oracle, ALL rows against the dense
+    # encoder, idempotence, and row ranges that straddle 256-row blocks and the pass seam equal to the full call.
+    n, g, e = c3['n'], c3['g'], c3['e']
+    m, out, rows, truth = c3['m'], c3['out'], c3['rows'], c3['truth']
+    sp = cc.HipEncoder(e, g, 'cont', seed=4321, sparse=True)
+    got = sp.predict(m)
+    assert got.shape == (n, e) and np.all(np.isfinite(got))
+    assert max_rel(got[rows], truth) <= 1e-4
+    assert max_rel(got, out.astype(np.float64)) <= 2e-5                 # same fp32 sums in another order
+    assert np.array_equal(sp.predict(m), got)                           # idempotent, bit for bit
+    for lo, hi in ((256 * 100 - 7, 256 * 103 + 5), (65536 - 300, 65536 + 300), (99000, n), (0, 1), (n - 1, n)):
+        assert np.array_equal(encode_range(sp, m, lo, hi), got[lo:hi]), (lo, hi)
+    few = cc.HipEncoder(e, g, 'cont', seed=4321, sparse=True, batch_rows=1024)   # 8192-row sparse passes
+    assert np.array_equal(encode_range(few, m, 30000, 50000), got[30000:50000])
+
+
+def test_config5_fp16_encoder_at_one_ranks_shape(hip):
+    # configs[4]: one rank's encode, 62 500 cells x 33 000 genes with fp16 operands (bench --dtype f16 / `alt_f16`):
+    # two passes (32768 + 29732 rows, 1536-tile grids).  Sampled rows against the float64 evaluation of the
+    # once-rounded operands; the rows around the pass seam equal the same rows encoded alone; idempotence.
+    n, g, e = 62500, 33000, 64
+    m, (indptr, indices, values) = synth.synth_csr_device(n, g, seed=55)
+    enc = cc.HipEncoder(e, g, 'cont', seed=4321, dtype='f16')
+    out = enc.predict(m)
+    assert enc.fp32_fallback_passes() == 0
+    assert out.shape == (n, e) and np.all(np.isfinite(out)) and np.all(out > 0) and np.all(out < 1)
+    assert np.array_equal(enc.predict(m), out)
+    host = cc.CellMatrix(indptr.cpu().numpy(), indices.cpu().numpy(), values.cpu().numpy(), g)
+    rows = np.concatenate([np.random.default_rng(8).choice(n, 44, replace=False), [0, 32767, 32768, n - 1]])
+    assert max_rel(out[rows], eo.forward_f16('cont', enc.get_weights(), host.take(rows).to_dense())) <= 1e-4
+    seam = np.arange(32760, 32777)
+    assert np.array_equal(enc.predict(host.take(seam)), out[seam])
+    assert np.array_equal(encode_range(enc, m, 32760, 32777), out[32760:32777])
 
 
 def test_config4_shard_of_1m_candidates(hip, oracle_built):

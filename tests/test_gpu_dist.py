@@ -23,17 +23,21 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize('world,n', [(2, 1501), (3, 700)])
-def test_sharded_hip_path(hip, oracle_built, tmp_path, world, n):
+@pytest.mark.parametrize('world,n,mode', [(2, 1501, 'f32'), (3, 700, 'f32'), (2, 1501, 'sparse'), (2, 1501, 'f16x2'),
+                                          (2, 900, 'f16')])
+def test_sharded_hip_path(hip, oracle_built, tmp_path, world, n, mode):
+    """Every encoder mode under the sharded pipeline: a shard's encodings are the single-process encodings of the same
+    mode, bit for bit (a row's result depends neither on the rank nor on the pass it sits in)."""
     g, e, k = 2000, 32, 15
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={world}',
            '--master-addr', '127.0.0.1', '--master-port', str(free_port()),
-           os.path.join(ROOT, 'tests', '_gloo_gpu_worker.py'), str(tmp_path), str(n), str(g), str(e), str(k)]
+           os.path.join(ROOT, 'tests', '_gloo_gpu_worker.py'), str(tmp_path), str(n), str(g), str(e), str(k), mode]
     proc = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0'), capture_output=True,
                           text=True, timeout=900)
     assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
     full = synth.synth_csr(n, g, density=0.05, seed=99)
-    want_enc = cc.HipEncoder(e, g, 'cont', seed=5).predict(full)
+    want_enc = cc.HipEncoder(e, g, 'cont', seed=5, sparse=mode == 'sparse',
+                             dtype=mode if mode.startswith('f16') else 'f32').predict(full)
     want_i, want_d = ko.knn(want_enc, k)
     covered = 0
     for r in range(world):

@@ -18,7 +18,8 @@ def max_rel(got, truth):
 
 
 @pytest.mark.parametrize('arch,g,e', [('cont', 30000, 64), ('cls', 30000, 10), ('cont', 2500, 16), ('cont', 6000, 3),
-                                      ('cont', 12000, 32), ('cont', 11000, 130)])   # the last two: fused tail, 1 / 2 output tiles
+                                      ('cont', 12000, 32), ('cont', 11000, 130),   # fused tail, 1 / 2 output tiles
+                                      ('cont', 8000, 300)])                         # ... and 3 (encoding_size > 256)
 def test_low_latency_small_calls_match_the_oracle(hip, arch, g, e):
     m = synth.synth_csr(200, g, seed=g + e)
     ws = eo.glorot_weights(arch, e, g, seed=5, randomize_bn=True, bias_scale=0.05)

@@ -244,6 +244,44 @@ def test_enc_file_roundtrip_and_knn_fields(tmp_path):
     assert doc['nn'][0] == [1, 2] and len(doc['nd']) == 9
 
 
+def test_legacy_directory_import_keeps_the_rstrip_id_rule(tmp_path):
+    """reference import_encodings.py:66-77: ids are `name.rstrip('.enc')` — trailing CHARACTERS of {., e, n, c} go,
+    not the suffix — and the coordinates are then read from `<id>.enc`."""
+    from cellcomm_amd.recorder import MemoryDatabase
+    assert schema.legacy_iteration_id('5009.enc') == '5009'
+    assert schema.legacy_iteration_id('100e.enc') == '100'          # not '100e'
+    assert schema.legacy_iteration_id('49909.enc') == '49909'
+    assert schema.legacy_iteration_id('dec.enc') == 'd'
+    rng = np.random.default_rng(3)
+    barcodes = ['AAAC-1', 'AAAG-1', 'AACT-1', 'AAGT-1']
+    encs = {name: rng.random((4, 5), dtype=np.float32) for name in ('5009.enc', '100.enc', '100e.enc')}
+    for name, enc in encs.items():
+        schema.write_enc_file(tmp_path / name, enc)
+    (tmp_path / 'barcodes.tsv').write_text(''.join(b + '\n' for b in barcodes))
+    enc_dir = tmp_path / 'encodings'
+    enc_dir.mkdir()
+    for name in encs:
+        (tmp_path / name).rename(enc_dir / name)
+    in_order = lambda d: sorted(os.listdir(d))
+    docs = schema.legacy_import_directory(str(enc_dir), str(tmp_path / 'barcodes.tsv'), listdir=in_order)
+    assert [d['_id'] for d in docs] == ['100', '100', '5009']       # '100e.enc' collapsed onto '100' ...
+    assert docs[0] == docs[1] == schema.legacy_encs_document('100', encs['100.enc'], barcodes)   # ... and read 100.enc
+    assert docs[2]['xs'] == (encs['5009.enc'][:, 0] * np.float32(255)).tolist() and docs[2]['pids'] == [1, 2, 3, 4]
+    assert docs[2]['ns'] == barcodes and set(docs[2]) == {'_id', 'pids', 'ns', 'xs', 'ys', 'zs'}
+    db = MemoryDatabase()
+    with pytest.raises(KeyError):                                    # ... so a real collection refuses the second '100'
+        schema.legacy_import_directory(str(enc_dir), barcodes, collection=db['encs'], listdir=in_order)
+    db = MemoryDatabase()
+    one = schema.legacy_import_directory(str(enc_dir), barcodes, collection=db['encs'], listdir=lambda d: ['5009.enc'])
+    assert db['encs'].docs == one == docs[2:]
+    (enc_dir / '100.enc').unlink()                                   # now '100e.enc' points at a file that is not there
+    with pytest.raises(FileNotFoundError):
+        schema.legacy_import_directory(str(enc_dir), barcodes)
+    with pytest.raises(ValueError) as e:                             # the length check of import_encodings.py:57-58
+        schema.legacy_import_directory(str(enc_dir), barcodes[:3], listdir=lambda d: ['5009.enc'])
+    assert str(e.value) == 'Coordinates-/barcode-data different length: 3 != 4'
+
+
 # ---- BiGAN wrappers ----------------------------------------------------------------
 def _mock_bigan():
     gen, enc, disc = MagicMock(), MagicMock(), MagicMock()

@@ -86,6 +86,57 @@ def test_encoder_fixtures_match_oracle(path, oracle_built):
         assert np.max(np.abs(approx - out64) / np.abs(out64)) < 1e-5
 
 
+def torch_modules_forward(arch, ws, x, dtype):
+    """The same graphs out of torch.nn MODULES (torch's own Linear / BatchNorm1d(eps=1e-3).eval() / Sigmoid / Softmax):
+    a fourth statement of the Keras op definitions by the only other framework in this image that implements
+    BatchNormalization inference and softmax itself.  Layer order: reference src/bigan_cont.py:31-41,
+    src/bigan_classify.py:29-40.  (It does not pin the oracle to TensorFlow — nothing here can.)"""
+    import torch
+    from torch import nn
+
+    def dense(k, b):
+        lin = nn.Linear(k.shape[0], k.shape[1]).to(dtype)
+        with torch.no_grad():
+            lin.weight.copy_(torch.from_numpy(np.ascontiguousarray(k.T)))   # Keras kernels are [in x out]
+            lin.bias.copy_(torch.from_numpy(b))
+        return lin
+
+    xt = torch.from_numpy(np.asarray(x, dtype=np.float32)).to(dtype)        # predict() casts the input to float32 first
+    sig = nn.Sigmoid()
+    with torch.no_grad():
+        if arch == 'cont':
+            k1, b1, k2, b2, gamma, beta, mean, var, k3, b3, k4, b4, k5, b5 = ws
+            bn = nn.BatchNorm1d(len(gamma), eps=1e-3).to(dtype)
+            bn.weight.copy_(torch.from_numpy(gamma)); bn.bias.copy_(torch.from_numpy(beta))
+            bn.running_mean.copy_(torch.from_numpy(mean)); bn.running_var.copy_(torch.from_numpy(var))
+            bn.eval()
+            h = nn.Dropout(0.15).eval()(sig(dense(k1, b1)(xt)))
+            h = nn.Dropout(0.1).eval()(sig(dense(k2, b2)(torch.cat([h, xt], dim=-1))))
+            h = bn(h)
+            h = sig(dense(k3, b3)(h))
+            h = sig(dense(k4, b4)(h))
+            return sig(dense(k5, b5)(h)).numpy()
+        k1, b1, k2, b2, k3, b3, k4, b4 = ws
+        p = nn.Dropout(0.1).eval()(sig(dense(k1, b1)(xt)))
+        h = nn.Dropout(0.15).eval()(sig(dense(k2, b2)(p)))
+        h = sig(dense(k3, b3)(torch.cat([h, p], dim=-1)))
+        return nn.Softmax(dim=-1)(dense(k4, b4)(h)).numpy()
+
+
+@pytest.mark.parametrize('path', sorted(glob.glob(os.path.join(GOLDEN, 'encoder_*.npz'))))
+def test_encoder_fixtures_match_torch_modules(path):
+    import torch
+    z = np.load(path, allow_pickle=False)
+    arch, g, e, seed = str(z['arch']), int(z['G']), int(z['E']), int(z['seed'])
+    ws = eo.glorot_weights(arch, e, g, seed, randomize_bn=True, bias_scale=0.1)
+    if any(w.size == 0 for w in ws):
+        pytest.skip('degenerate widths (int(G*0.05) == 0): torch.nn.Linear with zero input features is covered by the oracle only')
+    out64 = torch_modules_forward(arch, ws, z['x'], torch.float64)
+    assert np.max(np.abs(out64 - z['out64']) / np.abs(z['out64'])) < 1e-12
+    out32 = torch_modules_forward(arch, ws, z['x'], torch.float32)
+    assert np.max(np.abs(out32 - z['out64']) / np.abs(z['out64'])) < 1e-5
+
+
 @pytest.mark.parametrize('name', ['knn_N257_E3.npz', 'knn_N2048_E32.npz', 'knn_N2048_E64.npz'])
 def test_knn_fixtures_match_oracle(name, oracle_built):
     z = load_npz(name)

@@ -55,6 +55,21 @@ def failing_calls(i, m, enc):
     other = cc.HipEncoder(8, g + 32, 'cls', seed=i)
     expect_failure(handle.cc_encode, other._h, m.device_handle(), None, 0, 4, out.ctypes.data)
     del other
+    # NULL handles / NULL buffers: refused with a message, nothing dereferenced
+    r, c = ctypes.c_int64(), ctypes.c_int64()
+    expect_failure(handle.cc_encode, None, m.device_handle(), None, 0, 4, out.ctypes.data)
+    expect_failure(handle.cc_encode, enc._h, None, None, 0, 4, out.ctypes.data)
+    expect_failure(handle.cc_encode, enc._h, m.device_handle(), None, 0, 4, None)
+    expect_failure(handle.cc_encode_dense, None, dense.ctypes.data, 4, out.ctypes.data)
+    expect_failure(handle.cc_gather_dense, None, None, 0, 4, g + 8, dense.ctypes.data, 0)
+    expect_failure(handle.cc_encoder_weight_shape, None, 0, ctypes.byref(r), ctypes.byref(c))
+    expect_failure(handle.cc_encoder_set_low_latency, None, 1)
+    expect_failure(handle.cc_encoder_set_sparse_input, None, 1)
+    expect_failure(handle.cc_encoder_set_batch, None, 64)
+    expect_failure(handle.cc_generate_dense, None, dense.ctypes.data, 4, dense.ctypes.data)
+    assert handle.cc_encoder_num_weights(None) == -1 and handle.cc_generator_num_weights(None) == -1
+    assert handle.cc_encoder_fp32_fallback_passes(None) == -1
+    expect_failure(handle.cc_knn_l2, None, 10, 8, 3, 0, oi.ctypes.data, od.ctypes.data)
 
 
 def cycle(i):

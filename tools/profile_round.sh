@@ -1,7 +1,9 @@
 #!/bin/bash
 # GPU-box helper: the evidence committed under profiles/ for a round (round 2 on).  Everything lands in
 # gpurun_out/profiles_<tag>/ with the names it keeps under profiles/:
-#   <tag>_bench_kernel_stats.csv / <tag>_bench_line_under_rocprof.json   rocprofv3 --kernel-trace --stats of the DEFAULT bench command
+#   <tag>_bench_kernel_stats.csv / <tag>_bench_line_under_rocprof.json   rocprofv3 --kernel-trace --stats of the default bench command
+#                                 + --no-dense-host (the dense-host side numbers launch the same layer-1 kernel on 4096-row
+#                                 and 32-row inputs outside the timed region, which would blur the per-kernel average)
 #   <tag>_pmc_hbm_traffic.json    FETCH_SIZE / WRITE_SIZE / TCC hit+miss per kernel, separate passes (bench.py replays the dominant kernel's traffic from it)
 #   <tag>_pmc_sq_dense.json       SQ counters + clock of the fp32 dense path (one 8192-row pass per launch)
 #   <tag>_pmc_sq_sparse.json      ... of the sparse first layer (16384 rows)
@@ -9,12 +11,12 @@
 #   <tag>_pmc_knn_c3.json / _c4rank.json      ... of the search at 100k x 100k and at one rank's 125k x 1M
 set -u
 cd "$(dirname "$0")/.."
-tag=${1:-r02}
+tag=${1:-r03}
 export TMPDIR=/tmp
 root=$PWD
 dst=$root/gpurun_out/profiles_$tag
 rm -rf "$dst"; mkdir -p "$dst"
-(cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$dst/stats" -- python3 $root/bench.py --steps 5 --warmup 1 >"$dst/${tag}_bench_line_under_rocprof.json" 2>"$dst/bench_stderr.log") || { echo "stats run failed"; tail -5 "$dst/bench_stderr.log"; exit 1; }
+(cd /tmp && timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$dst/stats" -- python3 $root/bench.py --steps 5 --warmup 1 --no-dense-host >"$dst/${tag}_bench_line_under_rocprof.json" 2>"$dst/bench_stderr.log") || { echo "stats run failed"; tail -5 "$dst/bench_stderr.log"; exit 1; }
 cp $(find "$dst/stats" -name '*kernel_stats.csv' | head -1) "$dst/${tag}_bench_kernel_stats.csv"
 rm -rf "$dst/stats"
 echo "stats done"; head -6 "$dst/${tag}_bench_kernel_stats.csv" | cut -c1-160

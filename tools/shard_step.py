@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """What one rank of a P-GPU run does per step, measured on one GPU: encode its 100k/P cells, then search
 its queries against 100k candidates (the other ranks' encodings are stand-ins already in HBM).  Everything
-but the all-gather itself, so N=1 time / this time is the scaling the collective can only lower."""
-import os, sys, time
+but the all-gather itself, so N=1 time / this time is the scaling the collective can only lower.
+
+  python3 tools/shard_step.py <mode> [out.json]     mode: f32 | sparse | f16x2 | f16; the JSON file is appended to
+                                                    (one key per mode), e.g. profiles/r03_shard_step.json"""
+import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -17,6 +20,7 @@ enc = cc.HipEncoder(E, G, 'cont', seed=4321, sparse=(mode == 'sparse'), dtype='f
 print('mode', mode, flush=True)
 full = torch.sigmoid(torch.randn((N, E), device='cuda'))
 base = None
+rows = []
 for P in (1, 2, 4, 8):
     n = -(-N // P)
     m, _ = synth.synth_csr_device(n, G, seed=1234)
@@ -36,4 +40,13 @@ for P in (1, 2, 4, 8):
     ms = (time.perf_counter() - t0) / 5 * 1e3
     base = base or ms
     print(f'P={P}: {n} cells per rank, {ms:.2f} ms per step -> {N / ms * 1e3:,.0f} cells/s if the all-gather were free, x{base / ms:.2f}  (first step {first:.1f} ms)', flush=True)
+    rows.append({'P': P, 'cells_per_rank': n, 'ms_per_step': round(ms, 3), 'speedup_vs_P1': round(base / ms, 3),
+                 'first_step_ms': round(first, 2)})
     del m
+if len(sys.argv) > 2:
+    path = sys.argv[2]
+    doc = json.load(open(path)) if os.path.exists(path) else {
+        'made_by': 'tools/shard_step.py', 'what': 'per-rank work of a P-GPU step of configs[2] measured on ONE GPU: encode '
+        '100k/P cells, D2H of the encodings, kNN of those queries against all 100k candidates; everything but the all-gather'}
+    doc[mode] = rows
+    json.dump(doc, open(path, 'w'), indent=1)
