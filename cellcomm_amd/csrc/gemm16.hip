@@ -32,9 +32,20 @@ namespace cc {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 
+// Experiment knobs (tools/gemm16_sweep.sh rebuilds with -D...; the defaults are the product)
+#ifndef CC_G16_TK1
+#define CC_G16_TK1 64      // K-step of the one-plane kernel
+#endif
+#ifndef CC_G16_NST1
+#define CC_G16_NST1 2      // LDS stages of the one-plane kernel
+#endif
+#ifndef CC_G16_RAWBAR
+#define CC_G16_RAWBAR 1    // K-step barrier as a bare s_barrier: __syncthreads() drains vmcnt(0) while LDS-DMA is in flight
+#endif
+
 constexpr int H_TM = 256, H_TN = 256, H_THREADS = 512;
 template <int PLANES> struct Cfg16 {
-  static constexpr int TK = PLANES == 1 ? 64 : 32;      // K-step
+  static constexpr int TK = PLANES == 1 ? CC_G16_TK1 : 32;      // K-step
   static constexpr int KQ = TK / 32;                    // MFMA k-chunks per K-step
   static constexpr int CH = TK / 8;                     // 16-byte chunks per A row
   static constexpr int STAGE_A = H_TM * TK * 2;
@@ -42,8 +53,9 @@ template <int PLANES> struct Cfg16 {
   static constexpr int STAGE = STAGE_A + PLANES * PLANE_B;
   static constexpr int A_INSTR = STAGE_A / 16 / H_THREADS;   // DMA instructions per thread and K-step for A
   static constexpr int B_INSTR = PLANE_B / 16 / H_THREADS;   // ... per weight plane
-  static constexpr int NSTAGE = PLANES == 1 ? 2 : 3;
+  static constexpr int NSTAGE = PLANES == 1 ? CC_G16_NST1 : 3;
   static constexpr int LDS = NSTAGE * STAGE;
+  static_assert(LDS <= 160 * 1024, "stages exceed the LDS of a CU");
 };
 
 struct Seg16 {
@@ -70,81 +82,202 @@ template <int CH> __device__ __forceinline__ int swz16(int row) {
   __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src),   \
                                    (void __attribute__((address_space(3))) *)(dst), 16, 0, 0)
 
+// The K-step barrier.  With more than one K-step of LDS-DMA in flight the barrier must not drain them: __syncthreads()
+// carries a fence that waits vmcnt(0) for pending LDS-DMA writes (the guide's "Pipelining across barriers"), so the
+// counted vmcnt of the 3-stage ring only works with the bare instruction.  Every wave's own LDS reads of the K-step
+// have been consumed by its MFMAs (or explicitly waited for, staggered waves) when it gets here.
+__device__ __forceinline__ void step_sync16() {
+#if CC_G16_RAWBAR
+#ifndef CC_G16_NOFENCE
+  asm volatile("" ::: "memory");   // no LDS access of the compiler's may cross the barrier in either direction
+#endif
+  __builtin_amdgcn_s_barrier();
+#ifndef CC_G16_NOFENCE
+  asm volatile("" ::: "memory");
+#endif
+#else
+  __syncthreads();
+#endif
+}
+
+// DMA sources of a K-segment: wave-uniform base pointers (SGPR pairs, advanced by scalar adds) plus per-lane byte
+// offsets that stay constant over the whole segment, so the K loop spends no vector instruction on addresses.
+template <int PLANES> struct Src16 {
+  const char *a_base[Cfg16<PLANES>::A_INSTR];   // row block i of the tile, K-step 0 of the segment
+  unsigned a_voff[Cfg16<PLANES>::A_INSTR];      // (row inside the block, swizzled chunk) of this lane
+  const char *b_base;                           // packed weight tile of K-step 0
+  unsigned b_voff;
+};
+
 // One K-segment: the DMA runs NSTAGE - 1 K-steps ahead, one barrier per K-step, everything drained at its end.
 // TWO: the segment multiplies W_lo as well as W_hi.  (A function template with the accumulators passed by reference:
 // as a lambda capturing them hipcc kept part of the state in scratch.)
 template <int PLANES, bool TWO>
-__device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], const _Float16 *(&a_src)[Cfg16<PLANES>::A_INSTR],
-                                               const _Float16 *b_src, int KT, char *smem,
-                                               const int (&a_off)[8][Cfg16<PLANES>::KQ], int b_off, int tid, int wave) {
+__device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], Src16<PLANES> src, int KT, char *smem,
+                                               const int (&a_off)[8][Cfg16<PLANES>::KQ], int b_off, int wave) {
   using C_ = Cfg16<PLANES>;
   constexpr int TK = C_::TK, KQ = C_::KQ, STAGE_A = C_::STAGE_A, PLANE_B = C_::PLANE_B, STAGE = C_::STAGE;
   constexpr int NSTAGE = C_::NSTAGE;
   constexpr int NPL = TWO ? 2 : 1;
   constexpr int DPS = C_::A_INSTR + NPL * C_::B_INSTR;     // DMA instructions per thread and K-step
-  auto issue = [&](int kt, int stage) {
+  auto issue = [&](int stage) {   // the next K-step not yet requested; `wave` is wave-uniform, so every LDS destination is scalar
     char *sa = smem + stage * STAGE, *sb = sa + STAGE_A;
 #pragma unroll
-    for (int i = 0; i < C_::A_INSTR; ++i) CC_GLDS16(a_src[i] + (int64_t)kt * TK, sa + (i * H_THREADS + wave * 64) * 16);
-    const _Float16 *bt = b_src + (int64_t)kt * (PLANES * TK * H_TN);
+    for (int i = 0; i < C_::A_INSTR; ++i) {
+      CC_GLDS16(src.a_base[i] + src.a_voff[i], sa + (i * H_THREADS + wave * 64) * 16);
+      src.a_base[i] += TK * 2;
+    }
 #pragma unroll
-    for (int i = 0; i < NPL * C_::B_INSTR; ++i) CC_GLDS16(bt + i * H_THREADS * 8, sb + (i * H_THREADS + wave * 64) * 16);
+    for (int i = 0; i < NPL * C_::B_INSTR; ++i)
+      CC_GLDS16(src.b_base + i * (H_THREADS * 16) + src.b_voff, sb + (i * H_THREADS + wave * 64) * 16);
+    src.b_base += PLANES * TK * H_TN * 2;
   };
 #pragma unroll
   for (int i = 0; i < NSTAGE - 1; ++i)
-    if (i < KT) issue(i, i);
+    if (i < KT) issue(i);
   if (KT >= NSTAGE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  step_sync16();
   int stage = 0;
-  for (int kt = 0; kt < KT; ++kt) {
-    // the stage written now was read one K-step ago at the latest, and every wave is past that barrier
-    if (kt + NSTAGE - 1 < KT) issue(kt + NSTAGE - 1, (stage + NSTAGE - 1) % NSTAGE);
-    const char *st = smem + stage * STAGE;
-    // A K-step is consumed in half-chunks (k-chunk kq, row half hf: 4 of the wave's 8 row blocks = 16 or 32 MFMAs).  The
-    // fragments of half-chunk i+1 are read from LDS BEFORE the MFMAs of half-chunk i are issued, so only the first
-    // read of a K-step (right behind the barrier) is exposed; the B fragments of a k-chunk serve both halves.
-    constexpr int NH = 2 * KQ;
-    h8 a[2][4], b[KQ > 1 ? 2 : 1][NPL][4];
-    auto load_a = [&](int kq, int hf, h8 (&dst)[4]) {
+  // A K-step is consumed in half-chunks (k-chunk kq, row half hf: 4 of the wave's 8 row blocks = 16 or 32 MFMAs).  The
+  // fragments of half-chunk i+1 are read from LDS BEFORE the MFMAs of half-chunk i are issued; the B fragments of a
+  // k-chunk serve both halves.
+  constexpr int NH = 2 * KQ;
+  auto mfma_half = [&](int hf, const h8 (&af)[4], const h8 (&bf)[NPL][4]) {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) dst[mt] = *reinterpret_cast<const h8 *>(st + a_off[4 * hf + mt][kq]);
-    };
-    auto load_b = [&](int kq, h8 (&dst)[NPL][4]) {
+    for (int p = 0; p < NPL; ++p)
 #pragma unroll
-      for (int p = 0; p < NPL; ++p)
+      for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt)
-          dst[p][nt] = *reinterpret_cast<const h8 *>(st + b_off + p * PLANE_B + kq * 16384 + nt * 256);
-    };
-    load_b(0, b[0]);
-    load_a(0, 0, a[0]);
+          acc[4 * hf + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[p][nt], acc[4 * hf + mt][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto load_a = [&](const char *st, int kq, int hf, h8 (&dst)[4]) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) dst[mt] = *reinterpret_cast<const h8 *>(st + a_off[4 * hf + mt][kq]);
+  };
+  auto load_b = [&](const char *st, int kq, h8 (&dst)[NPL][4]) {
+#pragma unroll
+    for (int p = 0; p < NPL; ++p)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        dst[p][nt] = *reinterpret_cast<const h8 *>(st + b_off + p * PLANE_B + kq * 16384 + nt * 256);
+  };
+  auto step_barrier = [&](int kt) {
+    // the next K-step's data must have landed; with three stages one more step may stay in flight
+    if (kt + NSTAGE - 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail: fewer steps in flight than the count assumes
+    step_sync16();
+  };
+  for (int kt = 0; kt < KT; ++kt) {
+    const char *st = smem + stage * STAGE;
+    h8 a[2][4], b[KQ > 1 ? 2 : 1][NPL][4];
+    // the first fragment reads go out right behind the barrier, the DMA requests of the K-step NSTAGE - 1 ahead
+    // follow (the stage they overwrite was read one K-step ago at the latest, and every wave is past that barrier)
+    load_b(st, 0, b[0]);
+    load_a(st, 0, 0, a[0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + NSTAGE - 1 < KT) issue((stage + NSTAGE - 1) % NSTAGE);
 #pragma unroll
     for (int hc = 0; hc < NH; ++hc) {
       const int kq = hc >> 1, hf = hc & 1;
       if (hc + 1 < NH) {
         const int nkq = (hc + 1) >> 1, nhf = (hc + 1) & 1;
-        if (nhf == 0) load_b(nkq, b[nkq & 1]);
-        load_a(nkq, nhf, a[(hc + 1) & 1]);
+        if (nhf == 0) load_b(st, nkq, b[nkq & 1]);
+        load_a(st, nkq, nhf, a[(hc + 1) & 1]);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int p = 0; p < NPL; ++p)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-            acc[4 * hf + mt][nt] =
-                __builtin_amdgcn_mfma_f32_16x16x32_f16(a[hc & 1][mt], b[KQ > 1 ? (kq & 1) : 0][p][nt], acc[4 * hf + mt][nt], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
+      mfma_half(hf, a[hc & 1], b[KQ > 1 ? (kq & 1) : 0]);
     }
-    // the next K-step's data must have landed; with three stages one more step may stay in flight
-    if (kt + NSTAGE - 1 < KT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tail: fewer steps in flight than the count assumes
-    __syncthreads();
+    step_barrier(kt);
     stage = (stage + 1) % NSTAGE;
   }
+}
+
+// The one-plane K-segment with the fragment reads and their waits placed by hand (CC_G16_HANDWAIT).  hipcc waits
+// lgkmcnt(0) in front of a half-chunk's MFMAs — i.e. also for the prefetch reads of the NEXT half-chunk issued just
+// above them — so each K-step exposed two full LDS round trips per wave.  Here the reads are inline asm (hipcc neither
+// counts nor waits for them; the guide's §5.7 form iii: "=v" loads, a wait-only statement, sched_barrier(0) before the
+// consumers) and every wait leaves the newest prefetch group in flight:
+//   R1 b0 a0 | DMA | R2 a1 | wait(4) MFMA a0 b0 | R3 b1 a0 | wait(8) MFMA a1 b0 | R4 a1 | wait(4) MFMA a0 b1 |
+//   wait(0) MFMA a1 b1 | vmcnt(0) barrier
+// Same MFMAs in the same order per accumulator as gemm16_segment: results are unchanged bit for bit.
+#ifndef CC_G16_HANDWAIT
+#define CC_G16_HANDWAIT 1
+#endif
+#define CC_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
+#define CC_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
+
+__device__ __forceinline__ void gemm16_segment_hand(f32x4 (&acc)[8][4], Src16<1> src, int KT, char *smem, int a_lane0,
+                                                    int a_lane1, int b_lane, int wave) {
+  using C_ = Cfg16<1>;
+  constexpr int TK = C_::TK, STAGE_A = C_::STAGE_A, STAGE = C_::STAGE, NSTAGE = C_::NSTAGE;
+  static_assert(C_::KQ == 2 && NSTAGE == 2, "hand-scheduled for K-step 64, two stages");
+  auto issue = [&](int stage) {
+    char *sa = smem + stage * STAGE, *sb = sa + STAGE_A;
+#pragma unroll
+    for (int i = 0; i < C_::A_INSTR; ++i) {
+      CC_GLDS16(src.a_base[i] + src.a_voff[i], sa + (i * H_THREADS + wave * 64) * 16);
+      src.a_base[i] += TK * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < C_::B_INSTR; ++i)
+      CC_GLDS16(src.b_base + i * (H_THREADS * 16) + src.b_voff, sb + (i * H_THREADS + wave * 64) * 16);
+    src.b_base += TK * H_TN * 2;
+  };
+  auto mfma_half = [&](int hf, const h8 (&af)[4], const h8 (&bf)[4]) {
+    __builtin_amdgcn_sched_barrier(0);   // nothing of this block above the wait in front of it
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[4 * hf + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[4 * hf + mt][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  if (KT > 0) issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  step_sync16();
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+  h8 a0[4], a1[4], b0[4], b1[4];
+  int stage = 0;
+  // fragment (kq, hf, mt) of A sits at a_lane<kq> + (4 hf + mt) * 2048, fragment (kq, nt) of B at b_lane + kq * 16384 +
+  // nt * 256 of a stage (b_lane includes the A part of the stage)
+#define CC_RD_A(dst, base, hf)                                                                             \
+  CC_DSR128(dst[0], base, (4 * (hf) + 0) * 2048); CC_DSR128(dst[1], base, (4 * (hf) + 1) * 2048);          \
+  CC_DSR128(dst[2], base, (4 * (hf) + 2) * 2048); CC_DSR128(dst[3], base, (4 * (hf) + 3) * 2048)
+#define CC_RD_B(dst, base, kq)                                                                             \
+  CC_DSR128(dst[0], base, (kq) * 16384 + 0); CC_DSR128(dst[1], base, (kq) * 16384 + 256);                  \
+  CC_DSR128(dst[2], base, (kq) * 16384 + 512); CC_DSR128(dst[3], base, (kq) * 16384 + 768)
+  for (int kt = 0; kt < KT; ++kt) {
+    const unsigned so = lds0 + stage * STAGE;
+    const unsigned va0 = so + a_lane0, va1 = so + a_lane1, vb = so + b_lane;
+    CC_RD_B(b0, vb, 0);
+    CC_RD_A(a0, va0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (kt + 1 < KT) issue(stage ^ 1);   // every wave is past the barrier behind its last read of that stage
+    __builtin_amdgcn_sched_barrier(0);
+    CC_RD_A(a1, va0, 1);
+    CC_LGKM(4);
+    mfma_half(0, a0, b0);
+    CC_RD_B(b1, vb, 1);
+    CC_RD_A(a0, va1, 0);
+    CC_LGKM(8);
+    mfma_half(1, a1, b0);
+    CC_RD_A(a1, va1, 1);
+    CC_LGKM(4);
+    mfma_half(0, a0, b1);
+    CC_LGKM(0);
+    mfma_half(1, a1, b1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    step_sync16();
+    stage ^= 1;
+  }
+#undef CC_RD_A
+#undef CC_RD_B
 }
 
 // PLANES: weight planes in the packed matrix (1: CC_DTYPE_F16, 2: CC_DTYPE_F16X2).
@@ -157,7 +290,7 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
   using C_ = Cfg16<PLANES>;
   constexpr int TK = C_::TK, KQ = C_::KQ, CH = C_::CH, STAGE_A = C_::STAGE_A;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   const int r16 = lane & 15, q = lane >> 4;
 
@@ -202,29 +335,47 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
     const Seg16 sg = segs.s[si];
     const int KT = sg.KT;
     if (KT == 0) continue;
-    const _Float16 *a_src[C_::A_INSTR];
+    Src16<PLANES> src;
 #pragma unroll
     for (int i = 0; i < C_::A_INSTR; ++i) {
-      const int64_t gr = m0 + a_row0 + i * ROWS_PER_INSTR;
-      a_src[i] = sg.A + (gr < M ? gr : M - 1) * sg.lda + a_chunk;
+      // rows beyond M re-read row M - 1 (their results are not stored): the clamp goes into the per-lane offset, which
+      // may then be negative relative to the block's (uniform) base row — unsigned wrap-around adds up correctly only
+      // in 64 bits, so the base row itself is clamped to stay at or below every lane's row
+      const int64_t blk = m0 + i * ROWS_PER_INSTR, gr = blk + a_row0;
+      const int64_t base_row = blk < M ? blk : M - 1;
+      const int64_t row = gr < M ? gr : M - 1;
+      src.a_base[i] = reinterpret_cast<const char *>(sg.A + base_row * sg.lda);
+      src.a_voff[i] = (unsigned)(((row - base_row) * sg.lda + a_chunk) * 2);
     }
-    const _Float16 *b_src = Wp + ((int64_t)n_tile * KTW + sg.wkt0) * (PLANES * TK * H_TN) + tid * 8;
+    src.b_base = reinterpret_cast<const char *>(Wp + ((int64_t)n_tile * KTW + sg.wkt0) * (PLANES * TK * H_TN));
+    src.b_voff = (unsigned)tid * 16u;
 
-    if (PLANES == 2 && sg.nterms == 2) gemm16_segment<PLANES, true>(acc, a_src, b_src, KT, smem, a_off, b_off, tid, wave);
-    else gemm16_segment<PLANES, false>(acc, a_src, b_src, KT, smem, a_off, b_off, tid, wave);
+    if constexpr (PLANES == 1 && C_::KQ == 2 && C_::NSTAGE == 2 && CC_G16_HANDWAIT) {
+      // the offsets of the other fragments are compile-time multiples: a row block further = 16 rows x 128 B
+      static_assert(CH == 8, "K-step 64: 8 chunks per row");
+      gemm16_segment_hand(acc, src, KT, smem, a_off[0][0], a_off[0][1], b_off, wave);
+    } else {
+      if (PLANES == 2 && sg.nterms == 2) gemm16_segment<PLANES, true>(acc, src, KT, smem, a_off, b_off, wave);
+      else gemm16_segment<PLANES, false>(acc, src, KT, smem, a_off, b_off, wave);
+    }
   }
 
   // epilogue: undo the weight scale, bias, activation.  Lane (r16, q) holds D[4q + j][r16] of every 16 x 16 block.
+  // (The lane id is laundered through an empty asm so that hipcc does not compute the epilogue's addresses and bias
+  // loads ahead of the K loop, where they cost registers the loop needs: it spilled 22 of them.)
+  int lane_e = lane;
+  asm volatile("" : "+v"(lane_e));
+  const int r16e = lane_e & 15, qe = lane_e >> 4;
 #pragma unroll
   for (int nt = 0; nt < 4; ++nt) {
-    const int col = n0 + wn * 64 + nt * 16 + r16;
+    const int col = n0 + wn * 64 + nt * 16 + r16e;
     const bool col_ok = col < N;
     const float bcol = col_ok ? bias[col] : 0.f;
 #pragma unroll
     for (int mt = 0; mt < 8; ++mt) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t row = m0 + wm * 128 + mt * 16 + 4 * q + j;
+        const int64_t row = m0 + wm * 128 + mt * 16 + 4 * qe + j;
         if (col_ok && row < M) {
           float z = acc[mt][nt][j] * inv_scale + bcol;
           z = (act == ACT_SIGMOID) ? sigmoid16_(z) : z;

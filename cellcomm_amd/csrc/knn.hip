@@ -1174,6 +1174,19 @@ __device__ __forceinline__ void collect16c_park(unsigned long long m64, int64_t 
 // barrier), one barrier per stage.  A stage's fragments are read at its start, and the QW MFMA chains of a block go
 // back to back into separate accumulators so that the sign tests of one group run under the MFMAs of the next.
 constexpr int C16C_NSTAGE = 4;
+// The stage barrier of the ring as the bare instruction: __syncthreads() carries a fence that waits vmcnt(0) while
+// LDS-DMA writes are pending, which drained the ring at every stage (round 3: the counted vmcnt in front of it was
+// followed by the fence's vmcnt(0) in the assembly).  Each wave's own fragment reads of the stage are consumed by its
+// MFMAs before it gets here, its own DMA pieces of the next stage are covered by the counted wait in front.
+__device__ __forceinline__ void knn_stage_barrier() {
+#ifdef CC_KNN_FENCED_BARRIER
+  __syncthreads();
+#else
+  asm volatile("" ::: "memory");   // the compiler moves no LDS access across the barrier
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+#endif
+}
 template <int ND>
 struct C16C {
   static constexpr int CB = ND == 1 ? 4 : ND == 2 ? 4 : ND == 4 ? 2 : 1;   // candidate blocks per stage
@@ -1271,7 +1284,7 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
   // stage 0 must have landed; NSTAGE - 2 later ones may stay in flight
   if (nstages >= NSTAGE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
   else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  knn_stage_barrier();
 
   int slot = 0;
   for (int64_t st = 0; st < nstages; ++st) {
@@ -1311,7 +1324,7 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     // the next stage's data must have landed (in the tail fewer stages are in flight than the count assumes)
     if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    knn_stage_barrier();
     slot = (slot + 1) % NSTAGE;
   }
   wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);

@@ -1,18 +1,27 @@
 #!/bin/bash
-# GPU-box helper: rebuild gemm16 with different knobs, time f16x2 and f16 encoder stages.
+# GPU-box helper: rebuild gemm16 with different knobs, time the fp16 encoder layers.
+#   tools/gemm16_sweep.sh "<EXTRA flags of variant 1>" "<variant 2>" ...      ("" = the product build)
+# SWEEP_SHAPES: bench flag sets, ';'-separated (default: one 32768-row pass at C3's width, and configs[4]'s rank shape)
 set -u
 cd "$(dirname "$0")/.."
+shapes=${SWEEP_SHAPES:---cells 32768;--cells 62500 --genes 33000 --k 50}
+dtypes=${SWEEP_DTYPES:-f16 f16x2}
 for v in "$@"; do
-  echo "=== variant: $v"
+  echo "=== variant: '$v'"
   rm -f cellcomm_amd/csrc/gemm16.o
   if ! make -C cellcomm_amd/csrc -j8 EXTRA="$v" >gpurun_out/sweep_build.log 2>&1; then tail -5 gpurun_out/sweep_build.log; continue; fi
-  for dt in f16x2 f16; do
-  timeout -k 10 200 python bench.py --cells ${SWEEP_CELLS:-32768} --steps 3 --warmup 1 --no-cpu-baseline --no-alt --dtype $dt 2>/dev/null | python -c "
+  IFS=';' read -ra SH <<< "$shapes"
+  for sh in "${SH[@]}"; do
+    for dt in $dtypes; do
+      timeout -k 10 200 python bench.py $sh --steps 5 --warmup 2 --no-cpu-baseline --no-alt --dtype $dt 2>/dev/null | python -c "
 import json,sys
 for l in sys.stdin:
     if l.startswith('{'):
         d=json.loads(l); s=d['stages_rank0']
-        print('$dt cells/s %.0f | L1 %.1f TF | L2 %.1f TF' % (d['value'], s['gemm_l1']['rate']/1e12, s['gemm_l2']['rate']/1e12))
+        print('$sh $dt: %.0f cells/s | L1 %.1f TF (%.3f ms/launch) | L2 %.1f TF' % (d['value'], s['gemm_l1']['rate']/1e12, s['gemm_l1']['ms_per_step']/s['gemm_l1']['launches']*d['steps'], s['gemm_l2']['rate']/1e12))
 "
+    done
   done
 done
+rm -f cellcomm_amd/csrc/gemm16.o
+make -C cellcomm_amd/csrc -j8 >gpurun_out/sweep_build.log 2>&1 || tail -5 gpurun_out/sweep_build.log
