@@ -600,12 +600,13 @@ __global__ __launch_bounds__(256, CC_KNN_COL_MINW) void knn_collect_kernel(
 }
 
 // ---- stage 1b on the fp16 matrix cores ------------------------------------------------------------
-// The collect pass only needs approximate distances with a KNOWN error bound (the certificate of
-// stage 2 absorbs it), so it can run on v_mfma_f32_32x32x16_f16 at 16x the fp32 MFMA rate with every
-// centred coordinate split as y·s = y_hi + y_lo (two fp16 values, s a power of two putting max|y·s| in
-// [2^6, 2^7)):  −2 q·c ≈ qh·ch + qh·cl + ql·ch (3·ND MFMAs, ND = ceil(d/16)); the two norms ride in
-// one extra K-step of the hi·hi product as three fp16 pieces each (33 bits).  13 MFMAs x 32 cycles per
-// 32 x 32 tile at d = 64 instead of 36 x 64.
+// Both passes of stage 1b only need approximate distances with a KNOWN error bound (the fine re-check and the
+// certificate of stage 2 absorb it), so they run on v_mfma_f32_32x32x16_f16 at 16x the fp32 MFMA rate on the centred
+// coordinates rounded to fp16, y·s -> fp16 (s a power of two putting max|y·s| in [2^6, 2^7)):  −2 q·c ≈ qh·ch
+// (ND MFMAs, ND = ceil(d/16)); the two norms ride in one extra K-step as three fp16 pieces each (33 bits).
+// 5 MFMAs x 32 cycles per 32 x 32 tile at d = 64 instead of 36 x 64.  (Rounds 1-2 also kept a three-product form,
+// qh·ch + qh·cl + ql·ch, 13 MFMAs, ~2^-22 accurate, first as the collect and then as a cross-check of the coarse
+// one; round 3 retired it: the fp32 list kernels are the one cross-check route.)
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 
 __device__ __forceinline__ void split3(float v, _Float16 *a, _Float16 *b, _Float16 *c) {
@@ -633,7 +634,6 @@ __device__ __forceinline__ h8 query_norm_unit(float v, int h) {
 //   t < ND          hi parts of (fac · y[16t + 8h + j]),  j = 0..7
 //   t == ND         norm step: h == 0 -> {n_a, n_b, n_c, 256, 256, 256, 0, 0} (candidate side) or
 //                                        {256, 256, 256, n_a, n_b, n_c, 0, 0} (query side); h == 1 -> 0
-//   t > ND          lo parts of K-step t − ND − 1
 __device__ __forceinline__ h8 panel16_unit(const float *__restrict__ x, const float *__restrict__ mu,
                                            const float *__restrict__ norms, int64_t i, bool valid, int d, int ND, int t,
                                            int h, float fac, float s2_over_256, bool query_side) {
@@ -651,25 +651,19 @@ __device__ __forceinline__ h8 panel16_unit(const float *__restrict__ x, const fl
     }
     return o;
   }
-  const bool lo = t > ND;
-  const int kt = lo ? t - ND - 1 : t;
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    const int k = 16 * kt + 8 * h + j;
-    if (k < d) {
-      const float v = fac * centred(x[i * d + k], mu[k]);
-      const _Float16 hi = (_Float16)v;
-      o[j] = lo ? (_Float16)(v - (float)hi) : hi;
-    }
+    const int k = 16 * t + 8 * h + j;
+    if (k < d) o[j] = (_Float16)(fac * centred(x[i * d + k], mu[k]));
   }
   return o;
 }
 
-// P16[((b·(2ND+1) + t)·64 + lane)] (16-byte units): candidate 32b + (lane&31), lane half = lane>>5
+// P16[((b·(ND+1) + t)·64 + lane)] (16-byte units): candidate 32b + (lane&31), lane half = lane>>5
 __global__ void knn_pack16_kernel(const float *__restrict__ x, const float *__restrict__ mu,
                                   const float *__restrict__ norms, int64_t N, int d, int ND, int64_t NB, float s,
                                   h8 *__restrict__ P16) {
-  const int NT = 2 * ND + 1;
+  const int NT = ND + 1;
   const int64_t total = NB * NT * 64;
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= total) return;
@@ -748,7 +742,7 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
     const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin,
     int64_t n_q, int include_self, float s, int S, int64_t NBs, int bstride, unsigned *__restrict__ out_key) {
-  constexpr int NT = 2 * ND + 1;
+  constexpr int NT = ND + 1;
   const int64_t tile = blockIdx.x / S;
   const int split = blockIdx.x % S;
   const int64_t b_lo = split * NBs;
@@ -918,145 +912,6 @@ __global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const unsigned 
   if (lane == 0) T[ql] = worst;
 }
 
-template <int ND>
-__device__ __forceinline__ void collect16_step(const h8 *__restrict__ sb, const h8 (&bqh)[ND + 1], const h8 (&bql)[ND],
-                                               int64_t b, int64_t NB, int64_t self_blk, int self_e, unsigned tail_vm,
-                                               float Ts, float inv_s2, WaveBuf &wb, u64 *__restrict__ buf,
-                                               int *__restrict__ cursor, int64_t q0, int64_t n_q, int cap, int lane) {
-  const int r = lane & 31, h = lane >> 5;
-  f32x16 acc;
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
-  h8 ah[ND + 1], al[ND];
-#pragma unroll
-  for (int t = 0; t <= ND; ++t) ah[t] = sb[t * 64 + lane];
-#pragma unroll
-  for (int t = 0; t < ND; ++t) al[t] = sb[(ND + 1 + t) * 64 + lane];
-#pragma unroll
-  for (int t = 0; t <= ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bqh[t], acc, 0, 0, 0);
-#pragma unroll
-  for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bql[t], acc, 0, 0, 0);
-#pragma unroll
-  for (int t = 0; t < ND; ++t) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bqh[t], acc, 0, 0, 0);
-  if (__any(b == self_blk) || b == NB - 1) {
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const bool kill = (b == self_blk && e == self_e) || (b == NB - 1 && !((tail_vm >> e) & 1u));
-      acc[e] = kill ? __builtin_nanf("") : acc[e];
-    }
-  }
-  park_passes(acc, Ts, inv_s2, (unsigned)(b * 32) + 4 * h, r, wb, buf, cursor, q0, n_q, cap, lane);
-}
-#ifndef CC_KNN_C16_MINW
-#define CC_KNN_C16_MINW 3
-#endif
-#ifndef CC_KNN_C16_CB
-#define CC_KNN_C16_CB 2
-#endif
-constexpr int C16_CB = CC_KNN_C16_CB;  // candidate blocks per LDS stage
-template <int ND>
-__global__ __launch_bounds__(256, CC_KNN_C16_MINW) void knn_collect16_kernel(
-    const h8 *__restrict__ P16, const float *__restrict__ norms, const float *__restrict__ x,
-    const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin, int64_t n_q, int include_self,
-    const float *__restrict__ T, float s, int S, int64_t NBs, int cap, u64 *__restrict__ buf,
-    int *__restrict__ cursor) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NT = 2 * ND + 1;
-  constexpr int BLK_U = NT * 64;             // 16-byte units per candidate block
-  constexpr int STAGE_U = C16_CB * BLK_U;
-  h8 *stage = reinterpret_cast<h8 *>(smem);  // [2][STAGE_U], then the 4 parking buffers
-
-  const int64_t tile = blockIdx.x / S;
-  const int split = blockIdx.x % S;
-  const int64_t b_lo = split * NBs;
-  const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int r = lane & 31, h = lane >> 5;
-  const int64_t ql = tile * 128 + wave * 32 + r;
-  const bool qvalid = ql < n_q;
-  const int64_t q = q_begin + ql;
-  const float s2 = s * s, inv_s2 = 1.0f / s2;
-
-  h8 bqh[ND + 1], bql[ND];
-#pragma unroll
-  for (int t = 0; t <= ND; ++t) bqh[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
-#pragma unroll
-  for (int t = 0; t < ND; ++t) bql[t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, ND + 1 + t, h, -2.0f * s, 0.f, true);
-  const float Ts = qvalid ? T[ql] * s2 : -INFINITY;
-  const int64_t q0 = tile * 128 + wave * 32;
-  WaveBuf wb;
-  wb.key = reinterpret_cast<u64 *>(smem + sizeof(h8) * 2 * STAGE_U) + wave * COL_WB;
-  wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * 2 * STAGE_U + sizeof(u64) * 4 * COL_WB) + wave * COL_WB;
-  wb.n = 0;
-
-  int64_t self_blk = -1;
-  int self_e = -1;
-  if (qvalid && !include_self) {
-    const int row = (int)(q & 31);
-    if (((row >> 2) & 1) == h) {
-      self_blk = q >> 5;
-      self_e = (row & 3) | ((row >> 3) << 2);
-    }
-  }
-  unsigned tail_vm = 0xffffu;
-#pragma unroll
-  for (int e = 0; e < 16; ++e)
-    if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
-
-  const int64_t nstages = (b_hi - b_lo + C16_CB - 1) / C16_CB;
-  const f32x4 *Pv = reinterpret_cast<const f32x4 *>(P16);
-  f32x4 *stage_v = reinterpret_cast<f32x4 *>(smem);
-  constexpr int NS = (STAGE_U + 255) / 256;
-  int s_cb[NS], s_off[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    int f = i * 256 + tid;
-    f = f < STAGE_U ? f : STAGE_U - 1;
-    s_cb[i] = f / BLK_U;
-    s_off[i] = f - s_cb[i] * BLK_U;
-  }
-  f32x4 rs[NS];
-#pragma unroll
-  for (int i = 0; i < NS; ++i) {
-    int64_t b = b_lo + s_cb[i];
-    b = b < b_hi ? b : b_hi - 1;
-    rs[i] = Pv[b * BLK_U + s_off[i]];
-  }
-#pragma unroll
-  for (int i = 0; i < NS; ++i) stage_v[s_cb[i] * BLK_U + s_off[i]] = rs[i];
-  __syncthreads();
-
-  int cur = 0;
-  for (int64_t st = 0; st < nstages; ++st) {
-    const bool more = st + 1 < nstages;
-    if (more) {
-#pragma unroll
-      for (int i = 0; i < NS; ++i) {
-        int64_t b = b_lo + (st + 1) * C16_CB + s_cb[i];
-        b = b < b_hi ? b : b_hi - 1;
-        rs[i] = Pv[b * BLK_U + s_off[i]];
-      }
-    }
-    const h8 *sbuf = stage + cur * STAGE_U;
-#pragma unroll
-    for (int cb = 0; cb < C16_CB; ++cb) {
-      const int64_t b = b_lo + st * C16_CB + cb;
-      if (b < b_hi)
-        collect16_step<ND>(sbuf + cb * BLK_U, bqh, bql, b, NB, self_blk, self_e, tail_vm, Ts, inv_s2, wb, buf, cursor, q0,
-                           n_q, cap, lane);
-    }
-    if (more) {
-      f32x4 *dbuf = stage_v + (cur ^ 1) * STAGE_U;
-#pragma unroll
-      for (int i = 0; i < NS; ++i) dbuf[s_cb[i] * BLK_U + s_off[i]] = rs[i];
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-  wavebuf_flush(wb, buf, cursor, q0, n_q, cap, lane);
-}
-
 // ---- stage 1b, coarse form of the collect (default) ------------------------------------------------------------
 // The 3-product tile above evaluates every (query, candidate) pair to ~2^-22, but only ~1.3 of a tile's 1024 pairs
 // pass the threshold.  Here the tile is the hi·hi product alone (ND + 1 MFMAs instead of 3·ND + 1: 5 instead of 13
@@ -1207,7 +1062,7 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     u64 *__restrict__ buf, int *__restrict__ cursor, int min_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C_ = C16C<ND>;
-  constexpr int NT = 2 * ND + 1;             // units per candidate block in the panel
+  constexpr int NT = ND + 1;                 // units per candidate block in the panel
   constexpr int CB = C_::CB, HU = C_::HU, STAGE_U = C_::STAGE_U, NU = C_::NU, DPS = C_::DPS, NSTAGE = C16C_NSTAGE;
   constexpr int QPW = 32 * QW;               // queries per wave
   h8 *stage = reinterpret_cast<h8 *>(smem);  // [NSTAGE][STAGE_U], then the 4 parking buffers
@@ -1747,7 +1602,7 @@ struct KnnWorkspace {
   bool use_fp16_select = CC_KNN_SELECT16 != 0;   // sample pass of stage 1b on the fp16 matrix cores too
   bool use_fp16_collect = true;            // stage 1b collect on the fp16 matrix cores when the data's scale allows
   bool use_fp64_prefilter = true;          // stage 3: float64 matrix-core prefilter in front of the exact scan
-  bool use_coarse_collect = true;          // stage 1b collect as hi·hi tile + direct fp32 re-evaluation of the parked pairs
+  bool use_coarse_collect = true;          // stage 1b collect on the fp16 tile + direct fp32 re-evaluation of the parked pairs; off: fp32 list collect
   int collect_splits = 0;                  // 0 = chosen per call; > 0 = forced (tools/knn_split_sweep.sh)
   int sample_splits = 0;                   // same for the candidate ranges of the fp16 sample pass
   int sample_stride = 0;                   // 0 = CC_KNN_SAMPLE; > 0 = every n-th candidate block is sampled
@@ -1842,30 +1697,6 @@ static int run_collect(int NG, const SelectArgs &a, const float *T, int S, int64
   return CC_OK;
 }
 
-static int run_collect16(int ND, const h8 *P16, const SelectArgs &a, const float *T, float s, int S, int64_t NBs,
-                         int cap, u64 *buf, int *cursor) {
-  const int64_t nwg = ceil_div(a.n_q, 128) * S;
-#define CC_C16(NDV)                                                                                           \
-  case NDV: {                                                                                                 \
-    const size_t lds = sizeof(h8) * 2 * C16_CB * (2 * NDV + 1) * 64 + (sizeof(u64) + sizeof(int)) * 4 * COL_WB; \
-    if (lds > 64 * 1024)                                                                                      \
-      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_collect16_kernel<NDV>),                  \
-                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-    hipLaunchKernelGGL(knn_collect16_kernel<NDV>, dim3((unsigned)nwg), dim3(256), lds, stream(), P16, a.norms, \
-                       a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, NBs, cap, buf,   \
-                       cursor);                                                                               \
-    break;                                                                                                    \
-  }
-  switch (ND) {
-    CC_C16(1) CC_C16(2) CC_C16(4) CC_C16(8)
-    default: CC_REQUIRE(false, "knn: no fp16 collect kernel for ND=%d", ND);
-  }
-#undef CC_C16
-  CC_HIP(hipGetLastError());
-  return CC_OK;
-}
-
-// split the NB candidate blocks into S contiguous ranges of NBs blocks (last may be short)
 static int run_collect16c(int ND, int QW, const h8 *P16, const SelectArgs &a, const unsigned *maxnorm_bits, const float *T,
                           float s, int S, int64_t NBs, int cap, u64 *buf, int *cursor) {
   const int64_t nwg = ceil_div(a.n_q, 128 * QW) * S;
@@ -2053,7 +1884,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
         }
       }
       if (scale16 > 0.f) {
-        const int64_t units = NB * (2 * ND16 + 1) * 64;
+        const int64_t units = NB * (ND16 + 1) * 64;
         if ((rc = P16.alloc(sizeof(h8) * (size_t)units))) return rc;
         hipLaunchKernelGGL(knn_pack16_kernel, dim3((unsigned)ceil_div(units, 256)), dim3(256), 0, stream(), d_x,
                            mu.as<float>(), norms.as<float>(), N, d, ND16, NB, scale16, P16.as<h8>());
@@ -2156,18 +1987,14 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
       if ((rc = cbuf.alloc(sizeof(u64) * (size_t)n_q * (size_t)col_cap))) return rc;
       if ((rc = ccur.alloc(sizeof(int) * (size_t)n_q))) return rc;
       CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
-      if (scale16 > 0.f) {
-        if (coarse) {
-          if ((rc = run_collect16c(ND16, QW, P16.as<h8>(), sa, maxn.as<unsigned>(), Tq.as<float>(), scale16, S, NBs, col_cap,
-                                   cbuf.as<u64>(), ccur.as<int>())))
-            return rc;
-        } else if ((rc = run_collect16(ND16, P16.as<h8>(), sa, Tq.as<float>(), scale16, S, NBs, col_cap, cbuf.as<u64>(),
-                                       ccur.as<int>())))
+      if (coarse) {
+        if ((rc = run_collect16c(ND16, QW, P16.as<h8>(), sa, maxn.as<unsigned>(), Tq.as<float>(), scale16, S, NBs, col_cap,
+                                 cbuf.as<u64>(), ccur.as<int>())))
           return rc;
-        // error bound of the fp16-split tile, relative to (‖q−μ‖² + ‖c−μ‖²), u = 2^-24:
-        //   16(3·ND+1) product terms accumulated in fp32 on |terms| summing to <= 3(‖q‖²+‖c‖²)
-        // + 12u  dropped lo·lo products and the 22-bit split of each coordinate
-        // + 4u   rounding of the centred coordinates;  twice the sum is used.
+        // The list holds exactly the pairs whose DIRECT fp32 distance is <= T (error ~d·2^-24 of the distance, far inside
+        // the fp32 bound above); the certificate keeps the wider bound rounds 1-2 derived for the three-product tile,
+        // relative to (‖q−μ‖² + ‖c−μ‖²), u = 2^-24: 16(3·ND+1) fp32-accumulated product terms on |terms| summing to
+        // <= 3(‖q‖²+‖c‖²), + 12u, + 4u for the centred coordinates; twice the sum.
         eps_coef = 2.0 * (3.0 * 16.0 * (3.0 * ND16 + 1.0) + 16.0) * 5.9604644775390625e-08;
       } else {
         if ((rc = pack_fp32_panels())) return rc;

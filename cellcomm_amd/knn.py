@@ -65,7 +65,8 @@ def use_fp16_collect(on):
 
 def use_coarse_collect(on):
     """Stage 1b collect as ONE fp16 product per pair + direct fp32 re-evaluation of the parked pairs (default), or
-    the three-product tile for every pair; same results, different speed (CC_KNN_OPT_COARSE_COLLECT)."""
+    every pair on the fp32 matrix cores (the cross-check route); same results, different speed
+    (CC_KNN_OPT_COARSE_COLLECT)."""
     _lib.check(_lib.lib().cc_knn_set_option(None, 6, 1 if on else 0))
 
 

@@ -200,7 +200,7 @@ int cc_knn_search_dev(void *knn, const float *dev_x, int64_t n_total, int d, int
 #define CC_KNN_OPT_FP16_SELECT 3       /* sample pass on the fp16 matrix cores (default 1)             */
 #define CC_KNN_OPT_FP64_PREFILTER 4    /* float64 matrix-core prefilter in stage 3 (default 1)         */
 #define CC_KNN_OPT_COLLECT_SPLITS 5    /* candidate splits of the collect pass; 0 = chosen per call    */
-#define CC_KNN_OPT_COARSE_COLLECT 6    /* collect as one fp16 product + fp32 re-check of survivors (1) */
+#define CC_KNN_OPT_COARSE_COLLECT 6    /* collect as one fp16 product + fp32 re-check of survivors (1); 0: fp32 list collect */
 #define CC_KNN_OPT_SAMPLE_SPLITS 7     /* candidate splits of the fp16 sample pass; 0 = chosen per call */
 #define CC_KNN_OPT_SAMPLE_STRIDE 8     /* every n-th candidate block feeds the threshold; 0 = default   */
 #define CC_KNN_OPT_SAMPLE_GROUPS 9     /* 32-query groups per wave of the fp16 sample pass; 0 = per call */

@@ -138,11 +138,12 @@ def test_few_uncertified_queries_scan_in_parallel(hip, oracle_built, n_q, k):
 
 
 @pytest.mark.parametrize('kind', ['uniform', 'far_from_origin', 'tight_clusters', 'dup_heavy', 'tiny_scale', 'mixed_scale'])
-def test_coarse_and_three_product_collect_agree(hip, oracle_built, kind):
+def test_coarse_and_fp32_list_collect_agree(hip, oracle_built, kind):
     """The collect pass keeps a pair when ONE fp16 product puts it within T + its error bound and the direct fp32
-    re-evaluation confirms it (default), or evaluates every pair with three products (option off): the neighbour
-    lists must be the oracle's either way, on data that stresses the coarse bound (large norms against small
-    distances, denormal-range coordinates, exact duplicates)."""
+    re-evaluation confirms it (default), or evaluates every pair on the fp32 matrix cores (option off: the one
+    cross-check route; rounds 1-2 also had a three-product fp16 form, retired in round 3): the neighbour lists must be
+    the oracle's either way, on data that stresses the coarse bound (large norms against small distances,
+    denormal-range coordinates, exact duplicates)."""
     rng = np.random.default_rng(len(kind))
     n, d, k = 9000, 64, 15
     if kind == 'uniform':
