@@ -82,7 +82,7 @@ while time.time() < t_end:
         if rng.random() < 0.3:
             m = cc.CellMatrix(m.indptr, m.indices, (m.values * rng.uniform(0.01, 3.0, len(m.values))).astype(np.float32), g)
         ws = eo.glorot_weights(arch, e, g, seed=int(rng.integers(1 << 30)), randomize_bn=True, bias_scale=0.2)
-        enc = cc.HipEncoder(e, g, arch, sparse=True)
+        enc = cc.HipEncoder(e, g, arch, sparse=True, batch_rows=[None, 16, 100][int(rng.integers(0, 3))])   # sparse passes of 65536 / 2048 rows
         enc.set_weights(ws)
         out = enc.predict(m)
         truth = eo.forward(arch, ws, m.to_dense())
