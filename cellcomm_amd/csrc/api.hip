@@ -296,23 +296,50 @@ static int encode_csr_sparse(Encoder *e, Csr *c, int64_t row_start, int64_t n, f
   if ((rc = encoder_ensure_all_rows(e, n < P ? n : P, true))) return rc;
   const double nnz_per_row = c->n_rows ? (double)c->nnz / (double)c->n_rows : 0.0;
   const int64_t end = row_start + n;
-  for (int64_t r0 = row_start; r0 < end;) {
-    const int64_t cut = r0 / SPMM_ROWS * SPMM_ROWS + P;
-    const int64_t r1 = cut < end ? cut : end, m = r1 - r0;
+  // rows [r0, r1) of the matrix through the layer stack; `at` = their offset inside the pass buffers
+  auto run_rows = [&](int64_t r0, int64_t r1, int64_t at) -> int {
+    const int64_t m = r1 - r0;
     const double nnz_hint = nnz_per_row * (double)m;
+    float *h1 = e->h1_all + at * e->ld1, *h2 = e->h2_all + at * e->ld2, *h3 = e->h3_all + at * e->ld3, *h4 = e->h4_all + at * e->ld3;
     float *out = dev_out + (r0 - row_start) * e->E;
-    if ((rc = launch_spmm(c->stream, r0, m, e->S1, nullptr, 0, e->h1_all, e->ld1, ACT_SIGMOID, CC_PROF_SPMM_L1, nnz_hint))) return rc;
+    int r;
+    if ((r = launch_spmm(c->stream, r0, m, e->S1, nullptr, 0, h1, e->ld1, ACT_SIGMOID, CC_PROF_SPMM_L1, nnz_hint))) return r;
     if (e->arch == CC_ARCH_CONT) {
       // layer 2 = sigmoid(h1 @ K2[:w0] + b2  (dense MFMA, linear)  +  x @ K2[w0:]  (sparse, adds the dense part, activates))
-      if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, m, e->L2a, e->h2_all, e->ld2, ACT_LINEAR, CC_PROF_GEMM_L2))) return rc;
-      if ((rc = launch_spmm(c->stream, r0, m, e->S2, e->h2_all, e->ld2, e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_SPMM_L2, nnz_hint))) return rc;
-      if ((rc = encoder_tail_cont(e, e->h2_all, m, e->h3_all, e->h4_all, out))) return rc;
-    } else {
-      if ((rc = launch_gemm(e->h1_all, e->ld1, nullptr, 0, m, e->L[1], e->h2_all, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return rc;
-      if ((rc = launch_gemm(e->h2_all, e->ld2, e->h1_all, e->ld1, m, e->L[2], e->h3_all, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return rc;
-      if ((rc = launch_gemm(e->h3_all, e->ld3, nullptr, 0, m, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return rc;
-      if ((rc = launch_row_softmax(out, m, e->E, e->E))) return rc;
+      if ((r = launch_gemm(h1, e->ld1, nullptr, 0, m, e->L2a, h2, e->ld2, ACT_LINEAR, CC_PROF_GEMM_L2))) return r;
+      if ((r = launch_spmm(c->stream, r0, m, e->S2, h2, e->ld2, h2, e->ld2, ACT_SIGMOID, CC_PROF_SPMM_L2, nnz_hint))) return r;
+      return encoder_tail_cont(e, h2, m, h3, h4, out);
     }
+    if ((r = launch_gemm(h1, e->ld1, nullptr, 0, m, e->L[1], h2, e->ld2, ACT_SIGMOID, CC_PROF_GEMM_L2))) return r;
+    if ((r = launch_gemm(h2, e->ld2, h1, e->ld1, m, e->L[2], h3, e->ld3, ACT_SIGMOID, CC_PROF_GEMM_TAIL, e->low_latency))) return r;
+    if ((r = launch_gemm(h3, e->ld3, nullptr, 0, m, e->L[3], out, e->E, ACT_LINEAR, CC_PROF_GEMM_TAIL))) return r;
+    return launch_row_softmax(out, m, e->E, e->E);
+  };
+  // Short ranges (a rank's shard at 4-8 GPUs: 12.5k rows are 49 row blocks x 12 panels = 2.3 rounds of layer-1
+  // workgroups at one workgroup per CU, then 1.15 rounds for layer 2): two halves, cut at a 256-row block, on the two
+  // library streams, so that the CUs one half leaves idle in its last round run workgroups of the other half.
+  const int64_t rb0 = row_start / SPMM_ROWS, nrb = ceil_div(end, SPMM_ROWS) - rb0;
+  const double rounds = (double)nrb * (double)e->S1.npan / 256.0;
+  if (n <= P && nrb >= 4 && rounds < 6.0) {
+    int64_t mid = (rb0 + nrb / 2) * SPMM_ROWS;
+    if (mid > row_start && mid < end) {
+      CC_HIP(hipStreamSynchronize(g_stream));   // buffer memsets of encoder_ensure_all_rows are on the library stream
+      struct StreamReset { ~StreamReset() { g_cur = nullptr; (void)hipStreamSynchronize(g_stream); (void)hipStreamSynchronize(g_stream2); } } guard;
+      g_cur = g_stream;
+      // (the launches of a half are stream-ordered; the two halves only share the read-only weights and the matrix)
+      const int rc_a = run_rows(row_start, mid, 0);
+      g_cur = g_stream2;
+      const int rc_b = rc_a ? rc_a : run_rows(mid, end, mid - row_start);
+      g_cur = nullptr;
+      CC_HIP(hipStreamSynchronize(g_stream2));
+      CC_HIP(hipStreamSynchronize(g_stream));
+      return rc_b;
+    }
+  }
+  for (int64_t r0 = row_start; r0 < end;) {
+    const int64_t cut = r0 / SPMM_ROWS * SPMM_ROWS + P;
+    const int64_t r1 = cut < end ? cut : end;
+    if ((rc = run_rows(r0, r1, 0))) return rc;
     r0 = r1;
   }
   CC_HIP(hipStreamSynchronize(stream()));
@@ -485,6 +512,17 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
     const int64_t each = round_up(ceil_div(rest, parts), GEMM_BM);
     for (int64_t i = 0; off < n; ++i, off += each) plan.push_back({off, (n - off < each) ? n - off : each, (int)(i & 1)});
     if (each > B) B = each;
+  } else if (e->dtype != CC_DTYPE_F32 && npass == 1 && n >= 2 * GEMM16_TILE &&
+             (double)ceil_div(n, GEMM16_TILE) * (double)e->L16[0].NT < 4.0 * 256.0) {
+    // fp16 kernels, one short pass (a rank's shard at 4-8 GPUs: 12.5k rows are 588 layer-1 tiles = 2.3 rounds at one
+    // 256 x 256 tile per CU, then 1.15 rounds of layer 2): two halves on the two streams fill each other's last rounds
+    // (x1.15-1.2 on the shard step).  Longer calls run whole rounds per pass and lose with a second stream (round 2:
+    // 36.4 -> 38.1 ms at C3), so they stay on one.
+    dual = true;
+    const int64_t each = round_up(ceil_div(n, 2), GEMM16_TILE);
+    plan.push_back({0, each, 0});
+    plan.push_back({each, n - each, 1});
+    B = each;
   } else {
     for (int64_t off = 0; off < n; off += B) plan.push_back({off, (n - off < B) ? n - off : B, 0});
   }

@@ -128,6 +128,7 @@ int launch_tail_small(const float *A, int64_t lda, int64_t M, const PackedWeight
 void gemm_small_release();
 
 // gemm16.hip — layers 1/2 on the fp16 matrix cores (CC_DTYPE_F16 / CC_DTYPE_F16X2)
+constexpr int GEMM16_TILE = 256;   // rows and columns of a workgroup's output tile (one workgroup per CU)
 struct PackedWeight16 {
   void *d_w = nullptr;      // [NT][KT][plane][TK / 8][256][8] fp16 (plane 0 = hi, plane 1 = lo)
   float *d_bias = nullptr;  // [NT*256]

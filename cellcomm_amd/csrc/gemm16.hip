@@ -43,7 +43,7 @@ using h8 = __attribute__((ext_vector_type(8))) _Float16;
 #define CC_G16_RAWBAR 1    // K-step barrier as a bare s_barrier: __syncthreads() drains vmcnt(0) while LDS-DMA is in flight
 #endif
 
-constexpr int H_TM = 256, H_TN = 256, H_THREADS = 512;
+constexpr int H_TM = GEMM16_TILE, H_TN = GEMM16_TILE, H_THREADS = 512;
 template <int PLANES> struct Cfg16 {
   static constexpr int TK = PLANES == 1 ? CC_G16_TK1 : 32;      // K-step
   static constexpr int KQ = TK / 32;                    // MFMA k-chunks per K-step
