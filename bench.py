@@ -60,6 +60,7 @@ def parse():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-alt', action='store_true',
                     help='skip the extra measurements reported under "alt" / "alt_f16" / "alt_sparse" / "dense_host"')
+    ap.add_argument('--alt-multi', action='store_true', help='run the "alt*" legs with --gpus N > 1 as well (default: N = 1 only)')
     ap.add_argument('--no-dense-host', action='store_true',
                     help='skip the dense-host side numbers (cc_encode_dense throughput, batch-32/128 latency); tools/profile_round.sh '
                          'passes it so that the per-kernel averages of the profiled run are those of the timed passes')
@@ -305,7 +306,8 @@ def main():
                'note': note}
         return leg, host_enc[:keep_rows].copy()
 
-    if args.dtype == 'f32' and not args.sparse and not args.no_alt:
+    # (N > 1: the side legs run only on request — a rank failing inside one would leave the others in a collective)
+    if args.dtype == 'f32' and not args.sparse and not args.no_alt and (world == 1 or args.alt_multi):
         alt, alt_samples['alt'] = gemm16_leg(
             'f16x2', 2, 'encoder layers 1-2 as v_mfma_f32_16x16x32_f16 on W = W_hi + W_lo (and A = A_hi + A_lo for the sigmoid '
                         'activations), fp32 accumulate; same 1e-4 parity bound as f32; not the headline')

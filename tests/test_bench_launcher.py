@@ -143,3 +143,20 @@ def test_bench_gpus_2_self_launch_on_one_device(hip):
     assert {'gather', 'gemm_l1', 'host_encode_ms', 'host_allgather_ms', 'host_knn_ms'} <= set(by_rank)
     assert all(v['max'] >= v['min'] >= 0 and 0 <= v['argmax_rank'] < 2 for v in by_rank.values())
     assert res['allgather_ms'] == by_rank['host_allgather_ms']
+
+
+@pytest.mark.gpu
+def test_bench_gpus_2_alt_legs_on_request(hip):
+    """The side legs (f16x2, f16, sparse) under two ranks, as `--alt-multi` runs them: every leg reports a value and the
+    line keeps its per-rank stage table."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    env.update(CC_BENCH_ONE_DEVICE='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                           '--cells', '5000', '--genes', '2000', '--latent', '16', '--no-cpu-baseline', '--alt-multi'],
+                          capture_output=True, text=True, env=env, timeout=900)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    res = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{')][-1])
+    assert res['n_gpus'] == 2 and 'stages_by_rank' in res
+    for leg in ('alt', 'alt_f16', 'alt_sparse'):
+        assert res[leg]['value'] > 0 and res[leg]['roofline']['achieved'] > 0, leg
+    assert 'dense_host' not in res                      # a one-GPU side number
