@@ -47,10 +47,15 @@ def main():
     lo, hi = pipeline.shard_bounds(n, world, rank)
     local = full.take(np.arange(lo, hi))
     res = pipeline.encode_and_knn(OracleEncoder('cont', e, g, 5), local, k, backend=OracleBackend())
-    # with the total known up front (no block-size exchange) the outcome is the same
-    res2 = pipeline.encode_and_knn(OracleEncoder('cont', e, g, 5), local, k, backend=OracleBackend(), n_total=n)
+    # with the total known up front (no block-size exchange) the outcome is the same; `timings` collects this rank's
+    # host-clock stages (what bench.py turns into stages_by_rank / allgather_ms)
+    timings = {}
+    res2 = pipeline.encode_and_knn(OracleEncoder('cont', e, g, 5), local, k, backend=OracleBackend(), n_total=n, timings=timings)
     assert np.array_equal(res2['idx'], res['idx']) and np.array_equal(res2['dist'], res['dist'])
     assert res2['q_begin'] == res['q_begin'] and res2['n_total'] == n
+    assert set(timings) == {'encode_ms', 'allgather_ms', 'knn_ms'} and all(v >= 0 for v in timings.values())
+    pipeline.encode_and_knn(OracleEncoder('cont', e, g, 5), local, k, backend=OracleBackend(), n_total=n, timings=timings)
+    assert all(v > 0 for v in timings.values())           # accumulated over calls
     try:
         pipeline.encode_and_knn(OracleEncoder('cont', e, g, 5), local, k, backend=OracleBackend(), n_total=n + world)
         raise SystemExit('a wrong n_total went unnoticed')
