@@ -29,6 +29,8 @@ void set_error(const char *fmt, ...) {
 hipStream_t stream() { return g_cur ? g_cur : g_stream; }
 bool initialised() { return g_stream != nullptr; }
 int init_generation() { return g_generation; }
+static int g_num_cus = 256;
+int num_cus() { return g_num_cus; }
 
 // ---- profiling ---------------------------------------------------------------
 struct ProfRec { int klass; double work; hipEvent_t e0, e1; };
@@ -616,6 +618,7 @@ int cc_init(int device) {
   CC_HIP(hipStreamCreateWithFlags(&g_stream2, hipStreamNonBlocking));
   g_cur = nullptr;
   g_device = device;
+  g_num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   ++g_generation;
   return CC_OK;
 }

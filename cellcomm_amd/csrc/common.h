@@ -19,6 +19,7 @@ bool initialised();
 // Counts successful cc_init calls that (re)created the library context: per-device one-time setup (kernel attributes)
 // is keyed on it, so it is redone after cc_shutdown + cc_init — possibly on another device.
 int init_generation();
+int num_cus();   // compute units of the device the library is initialised on
 
 // Kernel-class timers (HIP events on the library stream).
 struct ProfScope {

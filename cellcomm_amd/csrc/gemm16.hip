@@ -22,6 +22,8 @@
 // fragment reads of the 16x16x32 shape are bank-conflict free (the DMA writes linearly, so the swizzle is applied to
 // the per-lane global source address); a weight plane is packed as the linear LDS image [k / 8][256 columns][8 halfs].
 // With two planes the A fragments of a K-step are read once and used against W_hi and W_lo.
+// A last round of tiles that is at most half full (one workgroup per CU: rounds of 256) runs as 128-row tiles, two
+// workgroups per tile (template instance HALVES, launch_gemm16).
 // Measured on layer 1 (16384 x 30016 x 3072, random operands): one plane 1090 TFLOP/s (was 926 with the register-staged
 // 32x32x16 kernel of round 1), two planes 1330 executed (was 1042-1090) = 0.53 of the 2.5 PFLOP/s dense fp16 peak; the
 // 16x16x32 shape alone is worth +13-15 % over 32x32x16 at equal cycles (the chip holds a higher clock on it).
@@ -38,6 +40,9 @@ using h8 = __attribute__((ext_vector_type(8))) _Float16;
 #endif
 #ifndef CC_G16_NST1
 #define CC_G16_NST1 2      // LDS stages of the one-plane kernel
+#endif
+#ifndef CC_G16_HALFTAIL
+#define CC_G16_HALFTAIL 1  // a last round of tiles that is at most half full runs as half-height tiles on twice the CUs
 #endif
 #ifndef CC_G16_RAWBAR
 #define CC_G16_RAWBAR 1    // K-step barrier as a bare s_barrier: __syncthreads() drains vmcnt(0) while LDS-DMA is in flight
@@ -66,6 +71,10 @@ struct Seg16 {
   int nterms;          // 1: W_hi only, 2: W_hi and W_lo
 };
 struct Segs16 { Seg16 s[4]; int n; };
+
+// What a wave does in the K loop: its 128 x 64 share of a 256-row tile; nothing but DMA requests and barriers (all its
+// rows lie beyond M); or 64 x 64 of a half-height (128-row) tile, where all 8 waves stay busy.
+enum { W_FULL = 0, W_IDLE = 1, W_HALF = 2 };
 
 __device__ __forceinline__ float sigmoid16_(float z) { return 1.0f / (1.0f + expf(-z)); }
 
@@ -112,9 +121,9 @@ template <int PLANES> struct Src16 {
 // One K-segment: the DMA runs NSTAGE - 1 K-steps ahead, one barrier per K-step, everything drained at its end.
 // TWO: the segment multiplies W_lo as well as W_hi.  (A function template with the accumulators passed by reference:
 // as a lambda capturing them hipcc kept part of the state in scratch.)
-template <int PLANES, bool TWO>
+template <int PLANES, bool TWO, bool HALF>
 __device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], Src16<PLANES> src, int KT, char *smem,
-                                               const int (&a_off)[8][Cfg16<PLANES>::KQ], int b_off, int wave) {
+                                               const int (&a_off)[8][Cfg16<PLANES>::KQ], int b_off, int wave, int mode) {
   using C_ = Cfg16<PLANES>;
   constexpr int TK = C_::TK, KQ = C_::KQ, STAGE_A = C_::STAGE_A, PLANE_B = C_::PLANE_B, STAGE = C_::STAGE;
   constexpr int NSTAGE = C_::NSTAGE;
@@ -176,20 +185,34 @@ __device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], Src16<PLANES>
     h8 a[2][4], b[KQ > 1 ? 2 : 1][NPL][4];
     // the first fragment reads go out right behind the barrier, the DMA requests of the K-step NSTAGE - 1 ahead
     // follow (the stage they overwrite was read one K-step ago at the latest, and every wave is past that barrier)
-    load_b(st, 0, b[0]);
-    load_a(st, 0, 0, a[0]);
+    if (mode != W_IDLE) {
+      load_b(st, 0, b[0]);
+      load_a(st, 0, 0, a[0]);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (kt + NSTAGE - 1 < KT) issue((stage + NSTAGE - 1) % NSTAGE);
+    if (HALF && mode == W_HALF) {   // 64 rows of a half-height tile: row blocks 0-3 only (a_off already points at them)
 #pragma unroll
-    for (int hc = 0; hc < NH; ++hc) {
-      const int kq = hc >> 1, hf = hc & 1;
-      if (hc + 1 < NH) {
-        const int nkq = (hc + 1) >> 1, nhf = (hc + 1) & 1;
-        if (nhf == 0) load_b(st, nkq, b[nkq & 1]);
-        load_a(st, nkq, nhf, a[(hc + 1) & 1]);
+      for (int kq = 0; kq < KQ; ++kq) {
+        if (kq + 1 < KQ) {
+          load_b(st, kq + 1, b[(kq + 1) & 1]);
+          load_a(st, kq + 1, 0, a[(kq + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_half(0, a[kq & 1], b[KQ > 1 ? (kq & 1) : 0]);
       }
-      __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
-      mfma_half(hf, a[hc & 1], b[KQ > 1 ? (kq & 1) : 0]);
+    } else if (!HALF && mode == W_FULL) {   // (W_IDLE: no rows of the tile — the wave only feeds the DMA and keeps the barriers)
+#pragma unroll
+      for (int hc = 0; hc < NH; ++hc) {
+        const int kq = hc >> 1, hf = hc & 1;
+        if (hc + 1 < NH) {
+          const int nkq = (hc + 1) >> 1, nhf = (hc + 1) & 1;
+          if (nhf == 0) load_b(st, nkq, b[nkq & 1]);
+          load_a(st, nkq, nhf, a[(hc + 1) & 1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ahead of the MFMAs (hipcc sinks it otherwise)
+        mfma_half(hf, a[hc & 1], b[KQ > 1 ? (kq & 1) : 0]);
+      }
     }
     step_barrier(kt);
     stage = (stage + 1) % NSTAGE;
@@ -210,8 +233,9 @@ __device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], Src16<PLANES>
 #define CC_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define CC_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
+template <bool HALF>
 __device__ __forceinline__ void gemm16_segment_hand(f32x4 (&acc)[8][4], Src16<1> src, int KT, char *smem, int a_lane0,
-                                                    int a_lane1, int b_lane, int wave) {
+                                                    int a_lane1, int b_lane, int wave, int mode) {
   using C_ = Cfg16<1>;
   constexpr int TK = C_::TK, STAGE_A = C_::STAGE_A, STAGE = C_::STAGE, NSTAGE = C_::NSTAGE;
   static_assert(C_::KQ == 2 && NSTAGE == 2, "hand-scheduled for K-step 64, two stages");
@@ -255,23 +279,34 @@ __device__ __forceinline__ void gemm16_segment_hand(f32x4 (&acc)[8][4], Src16<1>
   for (int kt = 0; kt < KT; ++kt) {
     const unsigned so = lds0 + stage * STAGE;
     const unsigned va0 = so + a_lane0, va1 = so + a_lane1, vb = so + b_lane;
-    CC_RD_B(b0, vb, 0);
-    CC_RD_A(a0, va0, 0);
+    if (mode != W_IDLE) {
+      CC_RD_B(b0, vb, 0);
+      CC_RD_A(a0, va0, 0);
+    }
     __builtin_amdgcn_sched_barrier(0);
     if (kt + 1 < KT) issue(stage ^ 1);   // every wave is past the barrier behind its last read of that stage
     __builtin_amdgcn_sched_barrier(0);
-    CC_RD_A(a1, va0, 1);
-    CC_LGKM(4);
-    mfma_half(0, a0, b0);
-    CC_RD_B(b1, vb, 1);
-    CC_RD_A(a0, va1, 0);
-    CC_LGKM(8);
-    mfma_half(1, a1, b0);
-    CC_RD_A(a1, va1, 1);
-    CC_LGKM(4);
-    mfma_half(0, a0, b1);
-    CC_LGKM(0);
-    mfma_half(1, a1, b1);
+    if (HALF && mode == W_HALF) {   // 64 rows of a half-height tile: row blocks 0-3 only, both k-chunks
+      CC_RD_B(b1, vb, 1);
+      CC_RD_A(a1, va1, 0);
+      CC_LGKM(8);
+      mfma_half(0, a0, b0);
+      CC_LGKM(0);
+      mfma_half(0, a1, b1);
+    } else if (!HALF && mode == W_FULL) {   // (W_IDLE: no rows of the tile — the wave only feeds the DMA and keeps the barriers)
+      CC_RD_A(a1, va0, 1);
+      CC_LGKM(4);
+      mfma_half(0, a0, b0);
+      CC_RD_B(b1, vb, 1);
+      CC_RD_A(a0, va1, 0);
+      CC_LGKM(8);
+      mfma_half(1, a1, b0);
+      CC_RD_A(a1, va1, 1);
+      CC_LGKM(4);
+      mfma_half(0, a0, b1);
+      CC_LGKM(0);
+      mfma_half(1, a1, b1);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     step_sync16();
     stage ^= 1;
@@ -282,11 +317,12 @@ __device__ __forceinline__ void gemm16_segment_hand(f32x4 (&acc)[8][4], Src16<1>
 
 // PLANES: weight planes in the packed matrix (1: CC_DTYPE_F16, 2: CC_DTYPE_F16X2).
 // OUT_MODE 0: C fp32 [M x ldc];  1: C_hi (and C_lo when split) fp16 planes [M x ldc]
-template <int PLANES, int OUT_MODE>
+template <int PLANES, int OUT_MODE, bool HALVES>
 __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64_t M, const _Float16 *__restrict__ Wp,
                                                               const float *__restrict__ bias, float inv_scale,
                                                               int KTW, int N, int MT, int NT, void *__restrict__ C,
-                                                              void *__restrict__ C_lo, int64_t ldc, int act) {
+                                                              void *__restrict__ C_lo, int64_t ldc, int act, int tile0) {
+  constexpr bool halves = HALVES;
   using C_ = Cfg16<PLANES>;
   constexpr int TK = C_::TK, KQ = C_::KQ, CH = C_::CH, STAGE_A = C_::STAGE_A;
   extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -296,15 +332,22 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
 
   // XCD-aware grouped tile order: blockIdx % 8 = XCD under round-robin dispatch gets a contiguous slab of tiles,
   // 8 m-tiles share each weight tile consecutively
-  const int nwg = MT * NT, bid = blockIdx.x;
+  // A launch covers the tiles tile0 .. of that order.  `halves`: every tile is worked by TWO workgroups, each on 128
+  // of its 256 rows (8 waves as 2 x 4 of 64 x 64): the last, partly filled round of a product runs this way on twice
+  // the CUs (launch_gemm16).  A row's sums are the same MFMAs in the same order either way.
+  const int nwg = halves ? (int)(gridDim.x >> 1) : (int)gridDim.x, bid = halves ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
   const int xcd = bid & 7, qd = nwg >> 3, rem = nwg & 7;
-  const int wgid = (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
+  const int wgid = tile0 + (xcd < rem ? xcd * (qd + 1) : rem * (qd + 1) + (xcd - rem) * qd) + (bid >> 3);
   const int per_group = 8 * NT;
   const int first_m = (wgid / per_group) * 8;
   const int gsz = (MT - first_m < 8) ? MT - first_m : 8;
   const int m_tile = first_m + (wgid % per_group) % gsz;
   const int n_tile = (wgid % per_group) / gsz;
-  const int64_t m0 = (int64_t)m_tile * H_TM;
+  const int64_t m0 = (int64_t)m_tile * H_TM + (halves ? (int64_t)(blockIdx.x & 1) * (H_TM / 2) : 0);
+  if (m0 >= M) return;                                         // the lower half of a tile that has <= 128 rows
+  const int64_t m_lim = (halves && m0 + H_TM / 2 < M) ? m0 + H_TM / 2 : M;   // rows this workgroup computes: [m0, m_lim)
+  const int wrow = halves ? wm * 64 : wm * 128;                // first row of the wave inside the workgroup's rows
+  const int mode = m0 + wrow >= m_lim ? W_IDLE : (halves ? W_HALF : W_FULL);   // wave-uniform
   const int n0 = n_tile * H_TN;
 
   // per-thread DMA geometry: LDS unit L = i * 512 + tid of the A image is (row L / CH, slot L % CH) and takes the
@@ -325,7 +368,7 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
   int a_off[8][KQ];
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
-    const int row = wm * 128 + mt * 16 + r16;
+    const int row = wrow + mt * 16 + r16;   // (half-height tiles use row blocks 0-3 only)
 #pragma unroll
     for (int kq = 0; kq < KQ; ++kq) a_off[mt][kq] = (row * CH + ((4 * kq + q) ^ swz16<CH>(row))) * 16;
   }
@@ -342,8 +385,8 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
       // may then be negative relative to the block's (uniform) base row — unsigned wrap-around adds up correctly only
       // in 64 bits, so the base row itself is clamped to stay at or below every lane's row
       const int64_t blk = m0 + i * ROWS_PER_INSTR, gr = blk + a_row0;
-      const int64_t base_row = blk < M ? blk : M - 1;
-      const int64_t row = gr < M ? gr : M - 1;
+      const int64_t base_row = blk < m_lim ? blk : m_lim - 1;
+      const int64_t row = gr < m_lim ? gr : m_lim - 1;
       src.a_base[i] = reinterpret_cast<const char *>(sg.A + base_row * sg.lda);
       src.a_voff[i] = (unsigned)(((row - base_row) * sg.lda + a_chunk) * 2);
     }
@@ -353,10 +396,10 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
     if constexpr (PLANES == 1 && C_::KQ == 2 && C_::NSTAGE == 2 && CC_G16_HANDWAIT) {
       // the offsets of the other fragments are compile-time multiples: a row block further = 16 rows x 128 B
       static_assert(CH == 8, "K-step 64: 8 chunks per row");
-      gemm16_segment_hand(acc, src, KT, smem, a_off[0][0], a_off[0][1], b_off, wave);
+      gemm16_segment_hand<HALVES>(acc, src, KT, smem, a_off[0][0], a_off[0][1], b_off, wave, mode);
     } else {
-      if (PLANES == 2 && sg.nterms == 2) gemm16_segment<PLANES, true>(acc, src, KT, smem, a_off, b_off, wave);
-      else gemm16_segment<PLANES, false>(acc, src, KT, smem, a_off, b_off, wave);
+      if (PLANES == 2 && sg.nterms == 2) gemm16_segment<PLANES, true, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
+      else gemm16_segment<PLANES, false, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
     }
   }
 
@@ -375,8 +418,8 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
     for (int mt = 0; mt < 8; ++mt) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int64_t row = m0 + wm * 128 + mt * 16 + 4 * qe + j;
-        if (col_ok && row < M) {
+        const int64_t row = m0 + wrow + mt * 16 + 4 * qe + j;
+        if (col_ok && row < m_lim && (mt < 4 || !halves)) {
           float z = acc[mt][nt][j] * inv_scale + bcol;
           z = (act == ACT_SIGMOID) ? sigmoid16_(z) : z;
           if (OUT_MODE == 0) {
@@ -499,20 +542,38 @@ int launch_gemm16(const GemmSeg16 *segs, int nsegs, int64_t M, const PackedWeigh
   CC_REQUIRE(nwg < (int64_t)2147483647, "gemm16: grid too large");
   static int attr_gen = -1;   // per library context: redone after cc_shutdown + cc_init (maybe another device)
   if (attr_gen != init_generation()) {
-    CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<1, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<1>::LDS));
-    CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<1>::LDS));
-    CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<2>::LDS));
-    CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<2>::LDS));
+#define CC_ATTR16(PL, OM, HV) \
+  CC_HIP(hipFuncSetAttribute((const void *)gemm16_kernel<PL, OM, HV>, hipFuncAttributeMaxDynamicSharedMemorySize, Cfg16<PL>::LDS))
+    CC_ATTR16(1, 0, false); CC_ATTR16(1, 1, false); CC_ATTR16(2, 0, false); CC_ATTR16(2, 1, false);
+    CC_ATTR16(1, 0, true); CC_ATTR16(1, 1, true); CC_ATTR16(2, 0, true); CC_ATTR16(2, 1, true);
+#undef CC_ATTR16
     attr_gen = init_generation();
   }
   ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
   const _Float16 *wp = static_cast<const _Float16 *>(W.d_w);
   const int KTW = (int)(W.KT1 + W.KT2);
-#define CC_LAUNCH16(PL, OM)                                                                                          \
-  hipLaunchKernelGGL((gemm16_kernel<PL, OM>), dim3((unsigned)nwg), dim3(H_THREADS), Cfg16<PL>::LDS, stream(), sg, M, \
-                     wp, W.d_bias, 1.0f / W.scale, KTW, (int)W.N, (int)MT, (int)W.NT, C, C_lo, ldc, act)
-  if (W.planes == 1) { if (out_fp16) CC_LAUNCH16(1, 1); else CC_LAUNCH16(1, 0); }
-  else { if (out_fp16) CC_LAUNCH16(2, 1); else CC_LAUNCH16(2, 0); }
+  // One workgroup per CU: the product runs in rounds of g_num_cus tiles and its last round costs a whole tile time
+  // however few tiles it holds.  A last round that is at most half full runs as half-height tiles instead — two
+  // workgroups per tile, 128 rows each, on twice the CUs (0.6 of a tile time) — in a second launch behind the whole
+  // rounds.  (configs[4]'s N = 3300 is 13 column tiles, which no pass size turns into whole rounds.)
+  const int64_t cus = num_cus();
+  int64_t tail = nwg % cus;
+#if !CC_G16_HALFTAIL
+  tail = cus;
+#endif
+  const int64_t whole = (2 * tail <= cus) ? nwg - tail : nwg;   // tiles of the full-height launch
+#define CC_LAUNCH16(PL, OM, HV, GRID, TILE0)                                                                         \
+  hipLaunchKernelGGL((gemm16_kernel<PL, OM, HV>), dim3((unsigned)(GRID)), dim3(H_THREADS), Cfg16<PL>::LDS, stream(), \
+                     sg, M, wp, W.d_bias, 1.0f / W.scale, KTW, (int)W.N, (int)MT, (int)W.NT, C, C_lo, ldc, act,      \
+                     (int)(TILE0))
+#define CC_LAUNCH16_ALL(HV, GRID, TILE0)                                                                       \
+  do {                                                                                                         \
+    if (W.planes == 1) { if (out_fp16) CC_LAUNCH16(1, 1, HV, GRID, TILE0); else CC_LAUNCH16(1, 0, HV, GRID, TILE0); } \
+    else { if (out_fp16) CC_LAUNCH16(2, 1, HV, GRID, TILE0); else CC_LAUNCH16(2, 0, HV, GRID, TILE0); }               \
+  } while (0)
+  if (whole > 0) CC_LAUNCH16_ALL(false, whole, 0);
+  if (whole < nwg) CC_LAUNCH16_ALL(true, 2 * (nwg - whole), whole);
+#undef CC_LAUNCH16_ALL
 #undef CC_LAUNCH16
   CC_HIP(hipGetLastError());
   return CC_OK;
