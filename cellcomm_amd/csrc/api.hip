@@ -366,6 +366,11 @@ static int encoder_ensure_ws(Encoder *e, int64_t rows, int slots) {
     CC_HIP(hipMalloc(&e->d_row_ids[sl], sizeof(int64_t) * (size_t)rows));
     if (e->dtype != CC_DTYPE_F32) {
       e->ldxh = round_up(e->G, 64);
+#ifndef CC_NO_STRIDE_PAD
+      // a row stride within 8 KiB of a multiple of 64 KiB (G = 33000: 64.5 KiB) puts consecutive rows of an A tile on the
+      // same memory channels: layer 1 lost 2-5 % at configs[4]'s width.  One more 8 KiB of (never read) padding per row.
+      if ((e->ldxh * 2) % 65536 < 8192 || (e->ldxh * 2) % 65536 > 65536 - 8192) e->ldxh += 4096;
+#endif
       e->ld1h = e->w0 == 0 ? 64 : round_up(e->w0, 64);
       const size_t bx = sizeof(_Float16) * (size_t)(rows * e->ldxh), b1 = sizeof(_Float16) * (size_t)(rows * e->ld1h);
       CC_HIP(hipMalloc(&e->xh[sl], bx));

@@ -44,6 +44,9 @@ using h8 = __attribute__((ext_vector_type(8))) _Float16;
 #ifndef CC_G16_HALFTAIL
 #define CC_G16_HALFTAIL 1  // a last round of tiles that is at most half full runs as half-height tiles on twice the CUs
 #endif
+#ifndef CC_G16_PP
+#define CC_G16_PP 1        // one-plane K loop as the two-group ping-pong (gemm16_segment_pp); 0: gemm16_segment_hand
+#endif
 #ifndef CC_G16_RAWBAR
 #define CC_G16_RAWBAR 1    // K-step barrier as a bare s_barrier: __syncthreads() drains vmcnt(0) while LDS-DMA is in flight
 #endif
@@ -315,6 +318,129 @@ __device__ __forceinline__ void gemm16_segment_hand(f32x4 (&acc)[8][4], Src16<1>
 #undef CC_RD_B
 }
 
+// ---- the one-plane K-segment as a ping-pong of the two wave groups (CC_G16_PP; the guide's "8-phase" structure) ----
+// A K-step (64) is four phases of 16 MFMAs: (rows 0-63, k 0-31), (rows 64-127, k 0-31), (rows 0-63, k 32-63),
+// (rows 64-127, k 32-63) of the wave's 128 x 64 — the same MFMAs in the same order per accumulator as the other
+// segment forms.  Every phase is  [fragment reads + one 16 KiB DMA piece] s_barrier [lgkmcnt(0), 16 MFMAs] s_barrier,
+// and waves 4-7 run ONE barrier behind waves 0-3: while one group multiplies the other reads and requests, so each
+// SIMD (one wave of either group) always has exactly one wave in its MFMAs.
+// LDS stage (64 KiB, two of them): A as two k-half planes [k / 32][256 rows][4 chunks] (chunk swizzle swz16<4>) + the
+// weight image [k / 8][256][8] as packed.  The DMA pieces are the k-halves of A and of W: a piece of K-step t + 2 is
+// requested two phases after the last read of the region it overwrites, and is waited for (counted: three younger
+// pieces stay in flight) one phase before its first read:
+//   P1(t): request W k0 of t+1 | P2(t): A k1 of t+1, wait k1 of t | P3(t): W k1 of t+1 | P4(t): A k0 of t+2, wait k0 of t+1
+struct SrcPP {
+  const char *a_cur[2];   // row blocks 0-127 / 128-255 of the tile, K-step t of the segment (wave-uniform)
+  unsigned a_voff[2];     // (row inside the block, swizzled chunk of a k-half) of this lane, bytes
+  const char *b_cur;      // packed weight tile of K-step t
+  unsigned b_voff;
+};
+
+__device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src, int KT, char *smem, int a_lane, int b_lane,
+                                                  int wave, int wm) {
+  constexpr int STAGE = 65536, A_PLANE = 16384, B_OFF = 32768, B_HALF = 16384, A_STEP = 128, B_STEP = 32768;
+  // one DMA piece = 16 KiB = two instructions per thread
+  auto issue_a = [&](int step, int kq, int stage) {   // A k-half kq of K-step t + step
+    char *dst = smem + stage * STAGE + kq * A_PLANE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      CC_GLDS16(src.a_cur[i] + (step * A_STEP + kq * 64) + src.a_voff[i], dst + (i * H_THREADS + wave * 64) * 16);
+  };
+  auto issue_b = [&](int step, int kq, int stage) {   // weight k-half kq of K-step t + step
+    char *dst = smem + stage * STAGE + B_OFF + kq * B_HALF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      CC_GLDS16(src.b_cur + (step * B_STEP + kq * B_HALF + i * (H_THREADS * 16)) + src.b_voff,
+                dst + (i * H_THREADS + wave * 64) * 16);
+  };
+  auto mfma16 = [&](int hf, const h8 (&af)[4], const h8 (&bf)[4]) {
+    CC_LGKM(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[4 * hf + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[4 * hf + mt][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // prologue: K-step 0 whole, A k0 of K-step 1
+  if (KT > 0) { issue_a(0, 0, 0); issue_b(0, 0, 0); issue_a(0, 1, 0); issue_b(0, 1, 0); }
+  if (KT > 1) {
+    issue_a(1, 0, 1);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // k0 of K-step 0 has landed
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  bar();
+  if (wm) bar();   // waves 4-7 run one barrier behind
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+  h8 a0[4], a1[4], b[4];
+#define CC_PP_A(dst, base, kq, hf)                                                                           \
+  CC_DSR128(dst[0], base, (kq) * 16384 + (4 * (hf) + 0) * 1024); CC_DSR128(dst[1], base, (kq) * 16384 + (4 * (hf) + 1) * 1024); \
+  CC_DSR128(dst[2], base, (kq) * 16384 + (4 * (hf) + 2) * 1024); CC_DSR128(dst[3], base, (kq) * 16384 + (4 * (hf) + 3) * 1024)
+#define CC_PP_B(dst, base, kq)                                                                               \
+  CC_DSR128(dst[0], base, (kq) * 16384 + 0); CC_DSR128(dst[1], base, (kq) * 16384 + 256);                    \
+  CC_DSR128(dst[2], base, (kq) * 16384 + 512); CC_DSR128(dst[3], base, (kq) * 16384 + 768)
+  int stage = 0;
+  for (int t = 0; t < KT; ++t) {
+    const unsigned so = lds0 + stage * STAGE;
+    const unsigned va = so + a_lane, vb = so + b_lane;
+    const bool n1 = t + 1 < KT, n2 = t + 2 < KT;   // wave-uniform
+    // P1
+    CC_PP_B(b, vb, 0);
+    CC_PP_A(a0, va, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n1) issue_b(1, 0, stage ^ 1);
+    bar();
+    mfma16(0, a0, b);
+    bar();
+    // P2
+    CC_PP_A(a1, va, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n1) {
+      issue_a(1, 1, stage ^ 1);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // k1 of this K-step has landed (read in P3)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    mfma16(1, a1, b);
+    bar();
+    // P3
+    CC_PP_B(b, vb, 1);
+    CC_PP_A(a0, va, 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n1) issue_b(1, 1, stage ^ 1);
+    bar();
+    mfma16(0, a0, b);
+    bar();
+    // P4
+    CC_PP_A(a1, va, 1, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (n2) {
+      issue_a(2, 0, stage);
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");   // k0 of the next K-step has landed (read in its P1)
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    mfma16(1, a1, b);
+    bar();
+    src.a_cur[0] += A_STEP; src.a_cur[1] += A_STEP; src.b_cur += B_STEP;
+    stage ^= 1;
+  }
+  if (!wm) bar();   // waves 0-3 wait for the other group's last phase: every read of the stages is done
+#undef CC_PP_A
+#undef CC_PP_B
+}
+
 // PLANES: weight planes in the packed matrix (1: CC_DTYPE_F16, 2: CC_DTYPE_F16X2).
 // OUT_MODE 0: C fp32 [M x ldc];  1: C_hi (and C_lo when split) fp16 planes [M x ldc]
 template <int PLANES, int OUT_MODE, bool HALVES>
@@ -393,7 +519,25 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
     src.b_base = reinterpret_cast<const char *>(Wp + ((int64_t)n_tile * KTW + sg.wkt0) * (PLANES * TK * H_TN));
     src.b_voff = (unsigned)tid * 16u;
 
-    if constexpr (PLANES == 1 && C_::KQ == 2 && C_::NSTAGE == 2 && CC_G16_HANDWAIT) {
+    if constexpr (PLANES == 1 && !HALVES && CC_G16_PP) {
+      static_assert(C_::TK == 64 && C_::LDS == 131072, "ping-pong: K-step 64, two 64 KiB stages");
+      SrcPP sp;
+      const int prow = tid >> 2;                                   // row inside a 128-row block
+      const int pchunk = ((tid & 3) ^ swz16<4>(prow)) << 3;        // halfs inside a k-half
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int64_t blk = m0 + i * 128, gr = blk + prow;
+        const int64_t base_row = blk < m_lim ? blk : m_lim - 1;
+        const int64_t row = gr < m_lim ? gr : m_lim - 1;
+        sp.a_cur[i] = reinterpret_cast<const char *>(sg.A + base_row * sg.lda);
+        sp.a_voff[i] = (unsigned)(((row - base_row) * sg.lda + pchunk) * 2);
+      }
+      sp.b_cur = src.b_base;
+      sp.b_voff = src.b_voff;
+      const int prow_w = wm * 128 + r16;
+      const int a_lane_pp = (prow_w * 4 + (q ^ swz16<4>(prow_w))) * 16;
+      gemm16_segment_pp(acc, sp, KT, smem, a_lane_pp, b_off, wave, wm);
+    } else if constexpr (PLANES == 1 && C_::KQ == 2 && C_::NSTAGE == 2 && CC_G16_HANDWAIT) {
       // the offsets of the other fragments are compile-time multiples: a row block further = 16 rows x 128 B
       static_assert(CH == 8, "K-step 64: 8 chunks per row");
       gemm16_segment_hand<HALVES>(acc, src, KT, smem, a_off[0][0], a_off[0][1], b_off, wave, mode);
