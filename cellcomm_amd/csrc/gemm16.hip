@@ -47,6 +47,9 @@ using h8 = __attribute__((ext_vector_type(8))) _Float16;
 #ifndef CC_G16_PP
 #define CC_G16_PP 1        // one-plane K loop as the two-group ping-pong (gemm16_segment_pp); 0: gemm16_segment_hand
 #endif
+#ifndef CC_G16_PP2
+#define CC_G16_PP2 1       // ... and the two-term segments of the two-plane kernel (gemm16_segment_pp2)
+#endif
 #ifndef CC_G16_RAWBAR
 #define CC_G16_RAWBAR 1    // K-step barrier as a bare s_barrier: __syncthreads() drains vmcnt(0) while LDS-DMA is in flight
 #endif
@@ -341,12 +344,18 @@ __device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src,
   constexpr int STAGE = 65536, A_PLANE = 16384, B_OFF = 32768, B_HALF = 16384, A_STEP = 128, B_STEP = 32768;
   // one DMA piece = 16 KiB = two instructions per thread
   auto issue_a = [&](int step, int kq, int stage) {   // A k-half kq of K-step t + step
+#if defined(CC_PP_NODMA) || defined(CC_PP_NOA)
+    return;
+#endif
     char *dst = smem + stage * STAGE + kq * A_PLANE;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       CC_GLDS16(src.a_cur[i] + (step * A_STEP + kq * 64) + src.a_voff[i], dst + (i * H_THREADS + wave * 64) * 16);
   };
   auto issue_b = [&](int step, int kq, int stage) {   // weight k-half kq of K-step t + step
+#if defined(CC_PP_NODMA) || defined(CC_PP_NOB)
+    return;
+#endif
     char *dst = smem + stage * STAGE + B_OFF + kq * B_HALF;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -356,13 +365,17 @@ __device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src,
   auto mfma16 = [&](int hf, const h8 (&af)[4], const h8 (&bf)[4]) {
     CC_LGKM(0);
     __builtin_amdgcn_sched_barrier(0);
+#ifndef CC_PP_NOPRIO
     __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         acc[4 * hf + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[4 * hf + mt][nt], 0, 0, 0);
+#ifndef CC_PP_NOPRIO
     __builtin_amdgcn_s_setprio(0);
+#endif
     __builtin_amdgcn_sched_barrier(0);
   };
   auto bar = [&]() {
@@ -388,6 +401,13 @@ __device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src,
 #define CC_PP_B(dst, base, kq)                                                                               \
   CC_DSR128(dst[0], base, (kq) * 16384 + 0); CC_DSR128(dst[1], base, (kq) * 16384 + 256);                    \
   CC_DSR128(dst[2], base, (kq) * 16384 + 512); CC_DSR128(dst[3], base, (kq) * 16384 + 768)
+#ifdef CC_PP_NOREAD
+#undef CC_PP_A
+#undef CC_PP_B
+#define CC_PP_A(dst, base, kq, hf) asm volatile("" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]) : "v"(base))
+#define CC_PP_B(dst, base, kq) asm volatile("" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]) : "v"(base))
+  for (int i = 0; i < 4; ++i) { a0[i] = h8{}; a1[i] = h8{}; b[i] = h8{}; }
+#endif
   int stage = 0;
   for (int t = 0; t < KT; ++t) {
     const unsigned so = lds0 + stage * STAGE;
@@ -433,12 +453,120 @@ __device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src,
     bar();
     mfma16(1, a1, b);
     bar();
+#ifndef CC_PP_SAMEK
     src.a_cur[0] += A_STEP; src.a_cur[1] += A_STEP; src.b_cur += B_STEP;
+#endif
     stage ^= 1;
   }
   if (!wm) bar();   // waves 0-3 wait for the other group's last phase: every read of the stages is done
 #undef CC_PP_A
 #undef CC_PP_B
+}
+
+// The two-plane form of the ping-pong (f16x2, segments that multiply W_hi and W_lo): K-step 32 through a ring of three
+// 48 KiB stages {A, W_hi, W_lo} (the layout of gemm16_segment), four phases per K-step — (rows 0-63, W_hi),
+// (rows 64-127, W_hi), (rows 0-63, W_lo), (rows 64-127, W_lo): per accumulator hi then lo of a K-step, as before.
+// Three DMA pieces per K-step, each requested two phases after the last read of what it overwrites, six younger
+// pieces in flight at either wait:
+//   P1(u): read W_hi, A rows 0-63 | request W_lo(u+2)        P2(u): read A rows 64-127 | wait: W_lo(u) has landed
+//   P3(u): read W_lo | request W_hi(u+3)                     P4(u): request A(u+3) | wait: W_hi, A of u+1 have landed
+// (One-term segments — the A_lo x W_hi product of layer 2, 4 % of its MFMAs — keep gemm16_segment.)
+__device__ __forceinline__ void gemm16_segment_pp2(f32x4 (&acc)[8][4], Src16<2> src, int NU, char *smem, int a_lane,
+                                                   int b_lane, int wave, int wm) {
+  using C_ = Cfg16<2>;
+  constexpr int NS = C_::NSTAGE, STAGE = C_::STAGE, STAGE_A = C_::STAGE_A, PLANE_B = C_::PLANE_B;
+  static_assert(NS == 3 && C_::TK == 32 && C_::A_INSTR == 2 && C_::B_INSTR == 2, "ring of three 48 KiB stages");
+  constexpr int A_STEP = C_::TK * 2, B_STEP = 2 * PLANE_B;
+  auto issue_a = [&](int x, int slot) {
+    char *dst = smem + slot * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      CC_GLDS16(src.a_base[i] + (int64_t)x * A_STEP + src.a_voff[i], dst + (i * H_THREADS + wave * 64) * 16);
+  };
+  auto issue_w = [&](int x, int plane, int slot) {
+    char *dst = smem + slot * STAGE + STAGE_A + plane * PLANE_B;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      CC_GLDS16(src.b_base + ((int64_t)x * B_STEP + plane * PLANE_B + i * (H_THREADS * 16)) + src.b_voff,
+                dst + (i * H_THREADS + wave * 64) * 16);
+  };
+  auto mfma16 = [&](int hf, const h8 (&af)[4], const h8 (&bf)[4]) {
+    CC_LGKM(0);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[4 * hf + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[4 * hf + mt][nt], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto bar = [&]() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  };
+  // prologue, in the order the counted waits assume: hi0 A0 lo0 hi1 A1 lo1 hi2 A2
+  issue_w(0, 0, 0); issue_a(0, 0); issue_w(0, 1, 0);
+  if (NU > 1) { issue_w(1, 0, 1); issue_a(1, 1); issue_w(1, 1, 1); }
+  if (NU > 2) { issue_w(2, 0, 2); issue_a(2, 2); }
+  if (NU > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // W_hi, A of K-step 0 have landed
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  bar();
+  if (wm) bar();   // waves 4-7 run one barrier behind
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
+  h8 a0[4], a1[4], bh[4], bl[4];
+#define CC_P2_A(dst, base, hf)                                                                   \
+  CC_DSR128(dst[0], base, (4 * (hf) + 0) * 1024); CC_DSR128(dst[1], base, (4 * (hf) + 1) * 1024); \
+  CC_DSR128(dst[2], base, (4 * (hf) + 2) * 1024); CC_DSR128(dst[3], base, (4 * (hf) + 3) * 1024)
+#define CC_P2_B(dst, base, plane)                                                                              \
+  CC_DSR128(dst[0], base, (plane) * 16384 + 0); CC_DSR128(dst[1], base, (plane) * 16384 + 256);                \
+  CC_DSR128(dst[2], base, (plane) * 16384 + 512); CC_DSR128(dst[3], base, (plane) * 16384 + 768)
+  static_assert(PLANE_B == 16384, "plane offset in the read macros");
+  int slot = 0, slot2 = 2;   // u % 3, (u + 2) % 3
+  for (int u = 0; u < NU; ++u) {
+    const unsigned so = lds0 + slot * STAGE;
+    const unsigned va = so + a_lane, vb = so + b_lane;
+    // P1
+    CC_P2_B(bh, vb, 0);
+    CC_P2_A(a0, va, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 2 < NU) issue_w(u + 2, 1, slot2);
+    bar();
+    mfma16(0, a0, bh);
+    bar();
+    // P2
+    CC_P2_A(a1, va, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 2 < NU) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // W_lo of this K-step has landed (read in P3)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bar();
+    mfma16(1, a1, bh);
+    bar();
+    // P3
+    CC_P2_B(bl, vb, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (u + 3 < NU) issue_w(u + 3, 0, slot);
+    bar();
+    mfma16(0, a0, bl);
+    bar();
+    // P4
+    if (u + 3 < NU) {
+      issue_a(u + 3, slot);
+      asm volatile("s_waitcnt vmcnt(12)" ::: "memory");   // W_hi, A of the next K-step have landed
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    bar();
+    mfma16(1, a1, bl);
+    bar();
+    slot = slot == NS - 1 ? 0 : slot + 1;
+    slot2 = slot2 == NS - 1 ? 0 : slot2 + 1;
+  }
+  if (!wm) bar();   // waves 0-3 wait for the other group's last phase: every read of the stages is done
+#undef CC_P2_A
+#undef CC_P2_B
 }
 
 // PLANES: weight planes in the packed matrix (1: CC_DTYPE_F16, 2: CC_DTYPE_F16X2).
@@ -542,7 +670,10 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
       static_assert(CH == 8, "K-step 64: 8 chunks per row");
       gemm16_segment_hand<HALVES>(acc, src, KT, smem, a_off[0][0], a_off[0][1], b_off, wave, mode);
     } else {
-      if (PLANES == 2 && sg.nterms == 2) gemm16_segment<PLANES, true, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
+      if constexpr (PLANES == 2 && !HALVES && CC_G16_PP2) {
+        if (sg.nterms == 2) gemm16_segment_pp2(acc, src, KT, smem, a_off[0][0], b_off, wave, wm);
+        else gemm16_segment<PLANES, false, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
+      } else if (PLANES == 2 && sg.nterms == 2) gemm16_segment<PLANES, true, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
       else gemm16_segment<PLANES, false, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
     }
   }

@@ -1,0 +1,14 @@
+#!/bin/bash
+# GPU-box helper: rebuild gemm16 with each flag set, time the fp16 encoder layers alone (tools/experiments/g16_ablate.py).
+#   tools/experiments/g16_ablate.sh "<flags 1>" "<flags 2>" ...     ABL_SHAPE="32768 30000 f16"
+set -u
+cd "$(dirname "$0")/../.."
+shape=${ABL_SHAPE:-32768 30000 f16}
+for v in "$@"; do
+  rm -f cellcomm_amd/csrc/gemm16.o
+  if ! make -C cellcomm_amd/csrc -j8 EXTRA="$v" >gpurun_out/abl_build.log 2>&1; then tail -5 gpurun_out/abl_build.log; continue; fi
+  printf "%-40s " "'$v'"
+  timeout -k 10 120 python tools/experiments/g16_ablate.py $shape 2>/dev/null
+done
+rm -f cellcomm_amd/csrc/gemm16.o
+make -C cellcomm_amd/csrc -j8 >gpurun_out/abl_build.log 2>&1 || tail -5 gpurun_out/abl_build.log
