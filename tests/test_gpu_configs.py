@@ -100,6 +100,29 @@ def test_config3_sparse_first_layer_at_the_size_the_bench_times_it(hip, c3):
     assert np.array_equal(encode_range(few, m, 30000, 50000), got[30000:50000])
 
 
+@pytest.mark.parametrize('dtype', ['f16', 'f16x2'])
+def test_config3_fp16_whole_rounds_equal_the_half_height_tiles(hip, c3, dtype):
+    """The fp16 kernels have two K loops: whole rounds of 256 x 256 tiles run the ping-pong of the two wave groups
+    (counted waits on LDS-DMA, csrc/gemm16.hip), a last round that is at most half full — and every call of a few
+    thousand rows — the 128-row tiles with the older loop.  Same MFMAs in the same order per accumulator: ALL rows of a
+    65536-row call (two passes of six whole rounds) must equal, bit for bit, the same rows encoded 2048 at a time
+    (96 layer-1 tiles: half-height only), and a second run of the long call.  A misplaced wait in the ping-pong shows
+    up here as a rare wrong tile."""
+    m, e, g = c3['m'], c3['e'], c3['g']
+    enc = cc.HipEncoder(e, g, 'cont', seed=4321, dtype=dtype)
+    n = 65536
+    whole = encode_range(enc, m, 0, n)
+    assert np.array_equal(encode_range(enc, m, 0, n), whole)
+    for lo in range(0, n, 2048):
+        part = encode_range(enc, m, lo, lo + 2048)
+        assert np.array_equal(part, whole[lo:lo + 2048]), f'{dtype}: rows {lo}..{lo + 2048} differ between the two K loops'
+    sel = c3['rows'] < n                                            # the sampled rows that fall into the range
+    rows = c3['rows'][sel]
+    truth = c3['truth'][sel] if dtype == 'f16x2' else eo.forward_f16('cont', enc.get_weights(), c3['host'].take(rows).to_dense())
+    assert sel.sum() >= 16 and max_rel(whole[rows], truth) <= 1e-4
+    assert enc.fp32_fallback_passes() == 0
+
+
 def test_config5_fp16_encoder_at_one_ranks_shape(hip):
     # configs[4]: one rank's encode, 62 500 cells x 33 000 genes with fp16 operands (bench --dtype f16 / `alt_f16`):
     # two passes (32768 + 29732 rows, 1536-tile grids).  Sampled rows against the float64 evaluation of the
