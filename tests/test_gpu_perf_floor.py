@@ -40,13 +40,14 @@ def test_kernel_rates_stay_above_their_floors(hip):
 
 def test_opt_in_paths_stay_above_their_floors(hip):
     """The sparse first layer and the fp16 matrix-core kernels (35 TFLOP/s on the non-zero products; one fp16 plane
-    1.28-1.35 PFLOP/s at 32768 rows since round 3, two planes 0.72-0.76 algorithmic)."""
+    1.41-1.44 PFLOP/s at 32768 rows since the ping-pong K loop of round 3, two planes 0.80 algorithmic)."""
     import torch
     n, g, e = 32768, 30000, 64
     m, _ = synth.synth_csr_device(n, g, seed=5)
     out = torch.empty((n, e), device='cuda')
-    # round 3: f16 1281-1346 TFLOP/s, f16x2 715-762 algorithmic (= 1429-1524 executed) at this shape
-    floors = {'sparse': ('spmm_l1', 20e12), 'f16': ('gemm_l1', 950e12), 'f16x2': ('gemm_l1', 530e12)}
+    # round 3: f16 1408-1437 TFLOP/s, f16x2 801 algorithmic (= 1603 executed) at this shape (1281-1346 / 715-762 before
+    # the ping-pong K loop)
+    floors = {'sparse': ('spmm_l1', 20e12), 'f16': ('gemm_l1', 1100e12), 'f16x2': ('gemm_l1', 620e12)}
     for mode, (stage, floor) in floors.items():
         enc = cc.HipEncoder(e, g, 'cont', seed=6, sparse=(mode == 'sparse'), dtype=mode if mode.startswith('f16') else 'f32')
         enc.predict_to_device(m, out.data_ptr(), 0, n)                    # warm-up: packs weights, builds the entry stream
