@@ -28,6 +28,8 @@ void set_error(const char *fmt, ...) {
 }
 hipStream_t stream() { return g_cur ? g_cur : g_stream; }
 bool initialised() { return g_stream != nullptr; }
+static bool g_two_streams = false;   // a call is running its passes on both library streams
+bool two_streams_active() { return g_two_streams; }
 int init_generation() { return g_generation; }
 static int g_num_cus = 256;
 int num_cus() { return g_num_cus; }
@@ -538,7 +540,8 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   const bool tail_once = e->arch == CC_ARCH_CONT && n > B;
   if (tail_once && (rc = encoder_ensure_all_rows(e, n, false))) return rc;
   if (dual) CC_HIP(hipStreamSynchronize(g_stream));   // workspace / h2_all memsets are on the library stream
-  struct StreamReset { ~StreamReset() { g_cur = nullptr; } } stream_reset;
+  struct StreamReset { ~StreamReset() { g_cur = nullptr; g_two_streams = false; } } stream_reset;
+  g_two_streams = dual;
   if (lead_passes > 0 && !g_lead_done) CC_HIP(hipEventCreateWithFlags(&g_lead_done, hipEventDisableTiming));
   int64_t pass_no = 0;
   for (const Pass &ps : plan) {

@@ -15,6 +15,7 @@ namespace cc {
 
 void set_error(const char *fmt, ...);
 hipStream_t stream();
+bool two_streams_active();   // the running call alternates its passes between the two library streams
 bool initialised();
 // Counts successful cc_init calls that (re)created the library context: per-device one-time setup (kernel attributes)
 // is keyed on it, so it is redone after cc_shutdown + cc_init — possibly on another device.
