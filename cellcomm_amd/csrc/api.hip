@@ -511,16 +511,19 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   bool dual = false;
   // (fp32 kernels only: 3 workgroups per CU leave room for the other stream's tiles; the fp16 kernels take a CU's
   // whole LDS per workgroup and gain nothing from a second stream — measured 36.4 -> 38.1 ms at C3)
-  if (npass >= 2 && npass <= 8 && e->dtype == CC_DTYPE_F32) {
+  // (a call that fits ONE pass of a width whose pass is larger than 8192 rows — 12288 at G = 20000 — but is longer
+  // than 8192 rows still runs as two halves: configs[1]'s 10k cells, 884k against 859k cells/s in one pass)
+  const int64_t np_dual = (npass == 1 && n > 8192) ? 2 : npass;
+  if (np_dual >= 2 && np_dual <= 8 && e->dtype == CC_DTYPE_F32) {
     dual = true;
-    const int64_t lead = npass <= 4 ? 0 : npass - 2;          // full-size passes in front
+    const int64_t lead = np_dual <= 4 ? 0 : np_dual - 2;          // full-size passes in front
     lead_passes = lead;
     int64_t off = 0;
     for (int64_t i = 0; i < lead; ++i, off += full) plan.push_back({off, full, 0});
-    const int64_t rest = n - off, parts = npass - lead;
+    const int64_t rest = n - off, parts = np_dual - lead;
     const int64_t each = round_up(ceil_div(rest, parts), GEMM_BM);
     for (int64_t i = 0; off < n; ++i, off += each) plan.push_back({off, (n - off < each) ? n - off : each, (int)(i & 1)});
-    if (each > B) B = each;
+    if (each > B || npass == 1) B = each;
   } else if (e->dtype != CC_DTYPE_F32 && npass == 1 && n >= 2 * GEMM16_TILE &&
              (double)ceil_div(n, GEMM16_TILE) * (double)e->L16[0].NT < 4.0 * 256.0) {
     // fp16 kernels, one short pass (a rank's shard at 4-8 GPUs: 12.5k rows are 588 layer-1 tiles = 2.3 rounds at one
@@ -669,6 +672,31 @@ int cc_synchronize(void) {
 }
 
 // ---- encoder -----------------------------------------------------------------------
+// Rows per pass.  GEMM time is quantised in rounds of resident tiles (fp32: 128 x 128, 3 per CU; fp16: 256 x 256, 1 per
+// CU), so the pass is the number of m-tiles whose layer-1 and layer-2 tile counts (weighted by their FLOP) fill whole
+// rounds best, searched from half to twice the default.  At G = 30000 the cont encoder keeps the defaults (8192 rows:
+// exactly 2 + 1 rounds; 32768 for the fp16 kernels: 6 + 3); the classify encoder (1000 columns = 8 n-tiles: 512 tiles
+// = 2/3 of a round at 8192 rows) takes 12288, configs[1]'s width (G = 20000) 12288, configs[4]'s (13 + 7 n-tiles) 45312.
+static int64_t default_pass_rows(const Encoder *e) {
+  const bool f32 = e->dtype == CC_DTYPE_F32;
+  const int64_t tm = f32 ? GEMM_BM : GEMM16_TILE, tn = f32 ? GEMM_BN : GEMM16_TILE;
+  const int64_t round = (f32 ? 3 : 1) * (int64_t)num_cus();
+  const int64_t def_mt = (f32 ? 8192 : 32768) / tm;
+  if (e->w0 <= 0 || e->w1 <= 0) return def_mt * tm;
+  const int64_t nt1 = ceil_div(e->w0, tn), nt2 = ceil_div(e->w1, tn);
+  const double f1 = (double)e->G * (double)e->w0;
+  const double f2 = (e->arch == CC_ARCH_CONT ? (double)(e->w0 + e->G) : (double)e->w0) * (double)e->w1;
+  auto fill = [&](int64_t tiles) { return (double)tiles / (double)(ceil_div(tiles, round) * round); };
+  auto eff = [&](int64_t mt) { return (f1 * fill(mt * nt1) + f2 * fill(mt * nt2)) / (f1 + f2); };
+  int64_t best = def_mt;
+  double best_eff = eff(def_mt) + 0.01;   // the default unless another size is worth more than 1 %
+  for (int64_t mt = def_mt / 2; mt <= 2 * def_mt; ++mt) {
+    const double v = eff(mt);
+    if (v > best_eff + 1e-9) { best = mt; best_eff = v; }
+  }
+  return best * tm;
+}
+
 int cc_encoder_create(int arch, int G, int E, int dtype, void **enc) {
   CC_REQUIRE(enc != nullptr, "enc is NULL");
   CC_REQUIRE(arch == CC_ARCH_CONT || arch == CC_ARCH_CLS, "unknown encoder arch %d", arch);
@@ -676,10 +704,8 @@ int cc_encoder_create(int arch, int G, int E, int dtype, void **enc) {
   CC_REQUIRE(G >= 1 && E >= 1, "gene_size=%d and encoding_size=%d must be >= 1", G, E);
   Encoder *e = new Encoder();
   e->arch = arch; e->G = G; e->E = E; e->dtype = dtype;
-  // rows per pass: 8192 rows are exactly 2 + 1 rounds of fp32 tiles (128 x 128, 3 per CU); the fp16 kernels (256 x 256
-  // tiles, 1 per CU) fill whole rounds with 32768: 1536 tiles = 6 rounds for layer 1, 768 = 3 for layer 2
-  e->batch = dtype == CC_DTYPE_F32 ? 8192 : 32768;
   encoder_shapes(e);
+  e->batch = default_pass_rows(e);
   *enc = e;
   return CC_OK;
 }
