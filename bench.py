@@ -298,7 +298,7 @@ def main():
                'roofline': {'kernel': f'gemm16_kernel (layer 1, {products} fp16 product(s) per algorithmic product)',
                             'bound': 'mfma', 'achieved': executed, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                             'frac': executed / PEAK_F16_MFMA_TFLOPS, 'traffic': None,
-                            'avg_launch_ms': a1['ms'] / max(a1['launches'], 1),
+                            'avg_launch_ms': a1['ms'] / max(a1['launches'], 1),   # a product whose last round of tiles is at most half full is two kernels (whole rounds + half-height tail)
                             'flop_per_launch': products * a1['work'] / max(a1['launches'], 1)},
                'fp32_fallback_passes': leg_enc.fp32_fallback_passes(),
                'stages_rank0': {k: {'launches': v['launches'], 'ms_per_step': v['ms'] / args.steps}
