@@ -893,16 +893,36 @@ __global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const unsigned 
     const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
     const float *xq = x + (q_begin + ql) * d;
     const int per_range = NSET * 32;
+    // The chosen keys sit anywhere in the wave's registers (a lane may hold several, most hold none): they are first
+    // compacted into a wave-private list, then ONE lane per candidate evaluates its distance — all of them at once
+    // instead of one dependent gather per register row (round 3: 0.30 -> 0.23 ms per 100k queries; the rest is the bisection).  The distance of a
+    // candidate is the same sequential fp32 sum as before (the collect's final test compares against exactly that).
+    __shared__ int64_t chosen[4][64];
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (int base = 0;; base += 64) {   // (more than 64 keys only when many agree in the compared bits)
+      int total = 0;                    // wave-uniform
 #pragma unroll
-    for (int j = 0; j < MAXR; ++j) {
-      if (j < nreg && key[j] <= prefix) {
-        const int slot = j * 64 + lane;
-        const int split = slot / per_range, sl = slot - split * per_range;
-        const int e = sl & 15, h = (sl >> 4) & 1;
-        const int64_t b = split * NBs + (int64_t)(key[j] & SKEY_MASK) * bstride;
-        const int64_t cand = b * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        worst = fmaxf(worst, fine_dist_batched(xq, x + cand * d, d, vec));
+      for (int j = 0; j < MAXR; ++j) {
+        if (j < nreg) {
+          const bool sel = key[j] <= prefix;
+          const unsigned long long bal = __ballot(sel);
+          const int pos = total + __builtin_popcountll(bal & below) - base;
+          if (sel && pos >= 0 && pos < 64) {
+            const int slot = j * 64 + lane;
+            const int split = slot / per_range, sl = slot - split * per_range;
+            const int e = sl & 15, h = (sl >> 4) & 1;
+            const int64_t b = split * NBs + (int64_t)(key[j] & SKEY_MASK) * bstride;
+            chosen[wave][pos] = b * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+          }
+          total += __builtin_popcountll(bal);
+        }
       }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the list is wave-private: its writes are done, no block barrier
+      const int here = total - base < 64 ? total - base : 64;
+      if (lane < here) worst = fmaxf(worst, fine_dist_batched(xq, x + chosen[wave][lane] * d, d, vec));
+      if (total - base <= 64) break;
+      __builtin_amdgcn_wave_barrier();
     }
   } else {
     worst = INFINITY;
