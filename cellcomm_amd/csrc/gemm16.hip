@@ -14,19 +14,20 @@
 // "multiply this A tile with W_hi and with W_lo", nterms = 1 "with W_hi only".  A 3-term input is
 // the two segments {A_hi, 2} and {A_lo, 1} over the same weight rows.
 //
-// Structure (round 2; prototype and measurements: tools/experiments/gemm16_dma.hip).  256 x 256 tile per 512-thread
-// workgroup, 8 waves as 2 x 4, 128 x 64 per wave = 8 x 4 blocks of 16 x 16 (128 accumulator registers).  Operands
-// reach LDS by LDS-DMA (global_load_lds, 16 bytes per lane, no staging registers), one barrier per K-step, the DMA
-// running 1 (one plane: K-step 64, two 64 KiB stages) or 2 (two planes: K-step 32, three 48 KiB stages) K-steps
-// ahead of the MFMAs.  A rows sit in LDS as 16-byte chunks whose index is XOR-swizzled by the row so that the
-// fragment reads of the 16x16x32 shape are bank-conflict free (the DMA writes linearly, so the swizzle is applied to
-// the per-lane global source address); a weight plane is packed as the linear LDS image [k / 8][256 columns][8 halfs].
-// With two planes the A fragments of a K-step are read once and used against W_hi and W_lo.
-// A last round of tiles that is at most half full (one workgroup per CU: rounds of 256) runs as 128-row tiles, two
-// workgroups per tile (template instance HALVES, launch_gemm16).
-// Measured on layer 1 (16384 x 30016 x 3072, random operands): one plane 1090 TFLOP/s (was 926 with the register-staged
-// 32x32x16 kernel of round 1), two planes 1330 executed (was 1042-1090) = 0.53 of the 2.5 PFLOP/s dense fp16 peak; the
-// 16x16x32 shape alone is worth +13-15 % over 32x32x16 at equal cycles (the chip holds a higher clock on it).
+// Structure.  256 x 256 tile per 512-thread workgroup (one per CU), 8 waves as 2 x 4, 128 x 64 per wave = 8 x 4 blocks of
+// 16 x 16 (128 accumulator registers).  Operands reach LDS by LDS-DMA (global_load_lds, 16 bytes per lane, no staging
+// registers) with counted vmcnt and bare s_barrier; A rows sit in LDS as 16-byte chunks whose index is XOR-swizzled by
+// the row so that the fragment reads of the 16x16x32 shape are bank-conflict free (the DMA writes linearly, so the
+// swizzle is applied to the per-lane global source address); a weight plane is packed as the linear LDS image
+// [k / 8][256 columns][8 halfs].  With two planes the A fragments of a K-step are used against W_hi and W_lo.
+// Which K loop runs (all of them issue the same MFMAs in the same order per accumulator: results do not depend on it):
+//   whole rounds of tiles, one plane      gemm16_segment_pp    ping-pong of the two wave groups, K-step 64, 2 x 64 KiB
+//   whole rounds, two planes, two terms   gemm16_segment_pp2   the same over K-step 32, 3 x 48 KiB {A, W_hi, W_lo}
+//   one-term segments (A_lo x W_hi)       gemm16_segment       round 2's loop: one barrier per K-step, DMA 2 steps ahead
+//   a last round at most half full, and   gemm16_kernel<.., HALVES>: 128-row tiles, two workgroups per tile, 8 waves as
+//   every call of a few thousand rows     2 x 4 of 64 x 64; gemm16_segment_hand (one plane) / gemm16_segment (two)
+// Measured on layer 1 at C3's width: one plane 1408-1437 TFLOP/s (round 1: 926 with a register-staged 32x32x16 kernel;
+// round 2: 1223-1251; round 3 before the ping-pong 1281-1346), two planes 1603-1650 executed; DESIGN.md §3 K2'.
 #include "common.h"
 
 namespace cc {
