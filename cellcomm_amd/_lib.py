@@ -41,6 +41,7 @@ SIGNATURES = {
     'cc_encoder_weight_shape': (c_int, [c_void_p, c_int, POINTER(c_int64), POINTER(c_int64)]),
     'cc_encoder_set_weights': (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int64]),
     'cc_encoder_set_batch': (c_int, [c_void_p, c_int64]),
+    'cc_encoder_batch': (c_int64, [c_void_p]),
     'cc_encoder_fp32_fallback_passes': (c_int64, [c_void_p]),
     'cc_encoder_set_sparse_input': (c_int, [c_void_p, c_int]),
     'cc_encoder_set_low_latency': (c_int, [c_void_p, c_int]),

@@ -598,7 +598,7 @@ using namespace cc;
 
 extern "C" {
 
-int cc_version(void) { return 103; }   // 103: NULL handles / buffers refused, sparse passes, wrapped indptr checked end to end (102: cc_shutdown, kNN workspace handles)
+int cc_version(void) { return 104; }   // 104: cc_encoder_batch, rows per pass chosen from the layer widths; 103: NULL handles / buffers refused, sparse passes, wrapped indptr checked end to end (102: cc_shutdown, kNN workspace handles)
 const char *cc_last_error(void) { return g_err.c_str(); }
 
 int cc_device_count(void) {
@@ -676,7 +676,7 @@ int cc_synchronize(void) {
 // CU), so the pass is the number of m-tiles whose layer-1 and layer-2 tile counts (weighted by their FLOP) fill whole
 // rounds best, searched from half to twice the default.  At G = 30000 the cont encoder keeps the defaults (8192 rows:
 // exactly 2 + 1 rounds; 32768 for the fp16 kernels: 6 + 3); the classify encoder (1000 columns = 8 n-tiles: 512 tiles
-// = 2/3 of a round at 8192 rows) takes 12288, configs[1]'s width (G = 20000) 12288, configs[4]'s (13 + 7 n-tiles) 45312.
+// = 2/3 of a round at 8192 rows) takes 12288, configs[1]'s width (G = 20000) 12288, configs[4]'s (13 + 7 n-tiles) 65536.
 static int64_t default_pass_rows(const Encoder *e) {
   const bool f32 = e->dtype == CC_DTYPE_F32;
   const int64_t tm = f32 ? GEMM_BM : GEMM16_TILE, tn = f32 ? GEMM_BN : GEMM16_TILE;
@@ -773,6 +773,11 @@ int cc_encoder_set_low_latency(void *enc, int on) {
 int64_t cc_encoder_fp32_fallback_passes(void *enc) {
   if (!enc) { set_error("encoder handle is NULL"); return -1; }
   return static_cast<Encoder *>(enc)->fallback_passes;
+}
+
+int64_t cc_encoder_batch(void *enc) {
+  if (!enc) { set_error("encoder handle is NULL"); return -1; }
+  return static_cast<Encoder *>(enc)->batch;
 }
 
 int cc_encoder_set_batch(void *enc, int64_t batch_rows) {

@@ -205,6 +205,11 @@ class HipEncoder:
             ids_ptr, row_start = ids.ctypes.data, 0
         _lib.check(lib.cc_encode_dev(self._h, x.device_handle(), ids_ptr, row_start, n, dev_out_ptr))
 
+    @property
+    def pass_rows(self):
+        """Rows per pass through the layer stack (chosen from the layer widths unless `batch_rows` was given)."""
+        return int(_lib.lib().cc_encoder_batch(self._h))
+
     def fp32_fallback_passes(self):
         """dtype 'f16x2': passes of the last predict whose input was not fp16-exact (ran in fp32)."""
         return int(_lib.lib().cc_encoder_fp32_fallback_passes(self._h))

@@ -83,11 +83,13 @@ int cc_encoder_weight_shape(void *enc, int idx, int64_t *rows, int64_t *cols);
 int cc_encoder_set_weights(void *enc, int idx, const float *host, int64_t rows, int64_t cols);
 /* Rows processed per pass through the layer stack.  Default: the number of rows whose layer-1 / layer-2 tiles fill whole
  * rounds of the chip best — 8192 for CC_DTYPE_F32 and 32768 for the fp16 dtypes at G = 30000, e.g. 12288 for the
- * classify encoder or at G = 20000, 45312 for fp16 at G = 33000 (between half and twice those defaults).
+ * classify encoder or at G = 20000, 65536 for fp16 at G = 33000 (between half and twice those defaults).
  * The sparse first layer runs passes of 8 x this many rows (rounded up to whole 256-row blocks; default 65536),
  * calls of more than 32 passes are processed in chunks of 32: device memory per call is bounded by the pass size,
  * and a row's result depends neither on the pass nor on the call it falls into. */
 int cc_encoder_set_batch(void *enc, int64_t batch_rows);
+/* The rows per pass in force (the default chosen at creation, or the last cc_encoder_set_batch); -1 for a NULL handle. */
+int64_t cc_encoder_batch(void *enc);
 /* Sparse first layer (CC_DTYPE_F32 encoders only, default off).  When on, cc_encode /
  * cc_encode_dev of a CONTIGUOUS row range (row_ids == NULL) never densify the counts: x @ K1 and the raw-input
  * rows of K2 (reference src/bigan_cont.py:32-35, src/bigan_classify.py:31) run as CSR x dense products in fp32 on

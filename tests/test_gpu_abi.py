@@ -255,7 +255,7 @@ def test_null_handles_and_buffers_are_refused(hip):
         assert fn(*args) == 1, fn.__name__
         assert text in lib.cc_last_error().decode(), (fn.__name__, lib.cc_last_error().decode())
     assert lib.cc_encoder_num_weights(None) == -1 and lib.cc_generator_num_weights(None) == -1
-    assert lib.cc_encoder_fp32_fallback_passes(None) == -1
+    assert lib.cc_encoder_fp32_fallback_passes(None) == -1 and lib.cc_encoder_batch(None) == -1
     lib.cc_encoder_free(None); lib.cc_csr_free(None); lib.cc_knn_free(None); lib.cc_generator_free(None)   # no-ops
     assert enc.predict(m).shape == (50, e)
 
@@ -314,3 +314,18 @@ def test_shutdown_then_init_reruns_the_per_context_kernel_setup(hip):
         assert lib.cc_knn_last_fallback_count() == 500       # the option outlived the shutdown
     finally:
         _lib.check(lib.cc_knn_set_option(None, 0, 0))
+
+
+def test_rows_per_pass_follow_the_layer_widths(hip):
+    """The default pass is the row count whose layer-1 / layer-2 tiles fill whole rounds of the chip (256 CUs: 768 fp32
+    tiles of 128 x 128, 256 fp16 tiles of 256 x 256): C3's width keeps the constants the headline was tuned with, other
+    widths move; an explicit `batch_rows` always wins.  (api.hip `default_pass_rows`.)"""
+    import cellcomm_amd as cc
+    assert cc.HipEncoder(64, 30000, 'cont').pass_rows == 8192            # 24 + 12 column tiles: 2 + 1 rounds
+    assert cc.HipEncoder(64, 30000, 'cont', dtype='f16').pass_rows == 32768    # 12 + 6: 6 + 3 rounds
+    assert cc.HipEncoder(64, 30000, 'cont', dtype='f16x2').pass_rows == 32768
+    assert cc.HipEncoder(10, 30000, 'cls').pass_rows == 12288            # 8 column tiles: 96 m-tiles = one round
+    assert cc.HipEncoder(32, 20000, 'cont').pass_rows == 12288           # 16 + 8: 2 + 1 rounds
+    assert cc.HipEncoder(64, 33000, 'cont', dtype='f16').pass_rows == 65536    # 13 + 7: 256 m-tiles = 13 + 7 rounds
+    assert cc.HipEncoder(8, 5, 'cont').pass_rows == 8192                 # degenerate widths (int(G * 0.1) == 0): the constant
+    assert cc.HipEncoder(64, 33000, 'cont', dtype='f16', batch_rows=1000).pass_rows == 1000

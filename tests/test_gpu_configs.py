@@ -125,8 +125,10 @@ def test_config3_fp16_whole_rounds_equal_the_half_height_tiles(hip, c3, dtype):
 
 def test_config5_fp16_encoder_at_one_ranks_shape(hip):
     # configs[4]: one rank's encode, 62 500 cells x 33 000 genes with fp16 operands (bench --dtype f16 / `alt_f16`):
-    # two passes (45312 + 17188 rows).  Sampled rows against the float64 evaluation of the
-    # once-rounded operands; the rows around the pass seam equal the same rows encoded alone; idempotence.
+    # ONE pass at this width's default (65536 rows: 13 + 7 column tiles fill whole rounds; the partial last round of the
+    # 62 500 rows runs as half-height tiles).  Sampled rows against the float64 evaluation of the once-rounded operands;
+    # the same call in 32768-row passes (the usual fp16 pass: a seam inside the range) returns the same bits, and the
+    # rows around that seam equal the same rows encoded alone; idempotence.
     n, g, e = 62500, 33000, 64
     m, (indptr, indices, values) = synth.synth_csr_device(n, g, seed=55)
     enc = cc.HipEncoder(e, g, 'cont', seed=4321, dtype='f16')
@@ -137,10 +139,13 @@ def test_config5_fp16_encoder_at_one_ranks_shape(hip):
     host = cc.CellMatrix(indptr.cpu().numpy(), indices.cpu().numpy(), values.cpu().numpy(), g)
     rows = np.concatenate([np.random.default_rng(8).choice(n, 44, replace=False), [0, 32767, 32768, n - 1]])
     assert max_rel(out[rows], eo.forward_f16('cont', enc.get_weights(), host.take(rows).to_dense())) <= 1e-4
-    for at in (32768, 45312):      # 45312 = 177 m-tiles: the pass this width gets (13 + 7 n-tiles fill 9 + 5 rounds); 32768: the usual one
-        seam = np.arange(at - 8, at + 9)
-        assert np.array_equal(enc.predict(host.take(seam)), out[seam])
-        assert np.array_equal(encode_range(enc, m, at - 8, at + 9), out[at - 8:at + 9])
+    assert enc.pass_rows == 65536
+    two = cc.HipEncoder(e, g, 'cont', seed=4321, dtype='f16', batch_rows=32768)
+    assert np.array_equal(two.predict(m), out)
+    seam = np.arange(32760, 32777)
+    for each in (enc, two):
+        assert np.array_equal(each.predict(host.take(seam)), out[seam])
+        assert np.array_equal(encode_range(each, m, 32760, 32777), out[32760:32777])
 
 
 def test_config4_shard_of_1m_candidates(hip, oracle_built):

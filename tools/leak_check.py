@@ -68,7 +68,7 @@ def failing_calls(i, m, enc):
     expect_failure(handle.cc_encoder_set_batch, None, 64)
     expect_failure(handle.cc_generate_dense, None, dense.ctypes.data, 4, dense.ctypes.data)
     assert handle.cc_encoder_num_weights(None) == -1 and handle.cc_generator_num_weights(None) == -1
-    assert handle.cc_encoder_fp32_fallback_passes(None) == -1
+    assert handle.cc_encoder_fp32_fallback_passes(None) == -1 and handle.cc_encoder_batch(None) == -1
     expect_failure(handle.cc_knn_l2, None, 10, 8, 3, 0, oi.ctypes.data, od.ctypes.data)
 
 
