@@ -20,12 +20,16 @@
 // the row so that the fragment reads of the 16x16x32 shape are bank-conflict free (the DMA writes linearly, so the
 // swizzle is applied to the per-lane global source address); a weight plane is packed as the linear LDS image
 // [k / 8][256 columns][8 halfs].  With two planes the A fragments of a K-step are used against W_hi and W_lo.
-// Which K loop runs (all of them issue the same MFMAs in the same order per accumulator: results do not depend on it):
-//   whole rounds of tiles, one plane      gemm16_segment_pp    ping-pong of the two wave groups, K-step 64, 2 x 64 KiB
-//   whole rounds, two planes, two terms   gemm16_segment_pp2   the same over K-step 32, 3 x 48 KiB {A, W_hi, W_lo}
-//   one-term segments (A_lo x W_hi)       gemm16_segment       round 2's loop: one barrier per K-step, DMA 2 steps ahead
-//   a last round at most half full, and   gemm16_kernel<.., HALVES>: 128-row tiles, two workgroups per tile, 8 waves as
-//   every call of a few thousand rows     2 x 4 of 64 x 64; gemm16_segment_hand (one plane) / gemm16_segment (two)
+// THREE K-loop forms (all issue the same MFMAs in the same order per accumulator: results do not depend on which runs):
+//   gemm16_segment_pp    whole rounds of tiles, one plane: ping-pong of the two wave groups, K-step 64, 2 x 64 KiB
+//   gemm16_segment_pp2   whole rounds, two planes, two-term segments: the same over K-step 32, 3 x 48 KiB {A, W_hi, W_lo}
+//   gemm16_segment       everything else — the half-height (128-row) tiles of a last round that is at most half full
+//                        and of every call of a few thousand rows (gemm16_kernel<.., HALVES>: two workgroups per tile,
+//                        8 waves as 2 x 4 of 64 x 64), and the one-term segments (A_lo x W_hi: 4 % of layer 2's MFMAs):
+//                        one barrier per K-step, the DMA NSTAGE - 1 steps ahead, fragment waits placed by hipcc
+// (Round 3 also carried a hand-waited one-plane form for the half-height tiles, +1.7 % on those tiles only, and a set
+// of result-destroying ablation switches inside this file; round 4 moved all of that to tools/experiments/
+// g16_ablations.patch — this translation unit has no build-time switches.)
 // Measured on layer 1 at C3's width: one plane 1408-1437 TFLOP/s (round 1: 926 with a register-staged 32x32x16 kernel;
 // round 2: 1223-1251; round 3 before the ping-pong 1281-1346), two planes 1603-1650 executed; DESIGN.md §3 K2'.
 #include "common.h"
@@ -35,29 +39,9 @@ namespace cc {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 using h8 = __attribute__((ext_vector_type(8))) _Float16;
 
-// Experiment knobs (tools/gemm16_sweep.sh rebuilds with -D...; the defaults are the product)
-#ifndef CC_G16_TK1
-#define CC_G16_TK1 64      // K-step of the one-plane kernel
-#endif
-#ifndef CC_G16_NST1
-#define CC_G16_NST1 2      // LDS stages of the one-plane kernel
-#endif
-#ifndef CC_G16_HALFTAIL
-#define CC_G16_HALFTAIL 1  // a last round of tiles that is at most half full runs as half-height tiles on twice the CUs
-#endif
-#ifndef CC_G16_PP
-#define CC_G16_PP 1        // one-plane K loop as the two-group ping-pong (gemm16_segment_pp); 0: gemm16_segment_hand
-#endif
-#ifndef CC_G16_PP2
-#define CC_G16_PP2 1       // ... and the two-term segments of the two-plane kernel (gemm16_segment_pp2)
-#endif
-#ifndef CC_G16_RAWBAR
-#define CC_G16_RAWBAR 1    // K-step barrier as a bare s_barrier: __syncthreads() drains vmcnt(0) while LDS-DMA is in flight
-#endif
-
 constexpr int H_TM = GEMM16_TILE, H_TN = GEMM16_TILE, H_THREADS = 512;
 template <int PLANES> struct Cfg16 {
-  static constexpr int TK = PLANES == 1 ? CC_G16_TK1 : 32;      // K-step
+  static constexpr int TK = PLANES == 1 ? 64 : 32;      // K-step
   static constexpr int KQ = TK / 32;                    // MFMA k-chunks per K-step
   static constexpr int CH = TK / 8;                     // 16-byte chunks per A row
   static constexpr int STAGE_A = H_TM * TK * 2;
@@ -65,7 +49,7 @@ template <int PLANES> struct Cfg16 {
   static constexpr int STAGE = STAGE_A + PLANES * PLANE_B;
   static constexpr int A_INSTR = STAGE_A / 16 / H_THREADS;   // DMA instructions per thread and K-step for A
   static constexpr int B_INSTR = PLANE_B / 16 / H_THREADS;   // ... per weight plane
-  static constexpr int NSTAGE = PLANES == 1 ? CC_G16_NST1 : 3;
+  static constexpr int NSTAGE = PLANES == 1 ? 2 : 3;
   static constexpr int LDS = NSTAGE * STAGE;
   static_assert(LDS <= 160 * 1024, "stages exceed the LDS of a CU");
 };
@@ -103,17 +87,9 @@ template <int CH> __device__ __forceinline__ int swz16(int row) {
 // counted vmcnt of the 3-stage ring only works with the bare instruction.  Every wave's own LDS reads of the K-step
 // have been consumed by its MFMAs (or explicitly waited for, staggered waves) when it gets here.
 __device__ __forceinline__ void step_sync16() {
-#if CC_G16_RAWBAR
-#ifndef CC_G16_NOFENCE
   asm volatile("" ::: "memory");   // no LDS access of the compiler's may cross the barrier in either direction
-#endif
   __builtin_amdgcn_s_barrier();
-#ifndef CC_G16_NOFENCE
   asm volatile("" ::: "memory");
-#endif
-#else
-  __syncthreads();
-#endif
 }
 
 // DMA sources of a K-segment: wave-uniform base pointers (SGPR pairs, advanced by scalar adds) plus per-lane byte
@@ -226,103 +202,16 @@ __device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], Src16<PLANES>
   }
 }
 
-// The one-plane K-segment with the fragment reads and their waits placed by hand (CC_G16_HANDWAIT).  hipcc waits
-// lgkmcnt(0) in front of a half-chunk's MFMAs — i.e. also for the prefetch reads of the NEXT half-chunk issued just
-// above them — so each K-step exposed two full LDS round trips per wave.  Here the reads are inline asm (hipcc neither
-// counts nor waits for them; the guide's §5.7 form iii: "=v" loads, a wait-only statement, sched_barrier(0) before the
-// consumers) and every wait leaves the newest prefetch group in flight:
-//   R1 b0 a0 | DMA | R2 a1 | wait(4) MFMA a0 b0 | R3 b1 a0 | wait(8) MFMA a1 b0 | R4 a1 | wait(4) MFMA a0 b1 |
-//   wait(0) MFMA a1 b1 | vmcnt(0) barrier
-// Same MFMAs in the same order per accumulator as gemm16_segment: results are unchanged bit for bit.
-#ifndef CC_G16_HANDWAIT
-#define CC_G16_HANDWAIT 1
-#endif
+// Inline-asm LDS reads of the ping-pong loops (the guide's §5.7 form iii: "=v" loads, a wait-only statement,
+// sched_barrier(0) in front of the consumers).  hipcc neither counts nor waits for them, and it believes the output is
+// written AT the statement while the hardware writes it when the LDS answers: every output MUST stay live until a
+// consumer behind the wait (a dead output's registers are reused at once — e.g. as the address pair of the next
+// global_load_lds — and the late data lands on top: round 3's `-DCC_PP_NOMFMA` ablation faulted the GPU exactly so,
+// tools/experiments/README.md).  tools/check_async_lds.py checks the built assembly for it (tests/test_cabi_symbols.py).
 #define CC_DSR128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(off))
 #define CC_LGKM(n) asm volatile("s_waitcnt lgkmcnt(" #n ")" ::: "memory")
 
-template <bool HALF>
-__device__ __forceinline__ void gemm16_segment_hand(f32x4 (&acc)[8][4], Src16<1> src, int KT, char *smem, int a_lane0,
-                                                    int a_lane1, int b_lane, int wave, int mode) {
-  using C_ = Cfg16<1>;
-  constexpr int TK = C_::TK, STAGE_A = C_::STAGE_A, STAGE = C_::STAGE, NSTAGE = C_::NSTAGE;
-  static_assert(C_::KQ == 2 && NSTAGE == 2, "hand-scheduled for K-step 64, two stages");
-  auto issue = [&](int stage) {
-    char *sa = smem + stage * STAGE, *sb = sa + STAGE_A;
-#pragma unroll
-    for (int i = 0; i < C_::A_INSTR; ++i) {
-      CC_GLDS16(src.a_base[i] + src.a_voff[i], sa + (i * H_THREADS + wave * 64) * 16);
-      src.a_base[i] += TK * 2;
-    }
-#pragma unroll
-    for (int i = 0; i < C_::B_INSTR; ++i)
-      CC_GLDS16(src.b_base + i * (H_THREADS * 16) + src.b_voff, sb + (i * H_THREADS + wave * 64) * 16);
-    src.b_base += TK * H_TN * 2;
-  };
-  auto mfma_half = [&](int hf, const h8 (&af)[4], const h8 (&bf)[4]) {
-    __builtin_amdgcn_sched_barrier(0);   // nothing of this block above the wait in front of it
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < 4; ++nt)
-        acc[4 * hf + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[4 * hf + mt][nt], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  if (KT > 0) issue(0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  step_sync16();
-  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char *)smem;
-  h8 a0[4], a1[4], b0[4], b1[4];
-  int stage = 0;
-  // fragment (kq, hf, mt) of A sits at a_lane<kq> + (4 hf + mt) * 2048, fragment (kq, nt) of B at b_lane + kq * 16384 +
-  // nt * 256 of a stage (b_lane includes the A part of the stage)
-#define CC_RD_A(dst, base, hf)                                                                             \
-  CC_DSR128(dst[0], base, (4 * (hf) + 0) * 2048); CC_DSR128(dst[1], base, (4 * (hf) + 1) * 2048);          \
-  CC_DSR128(dst[2], base, (4 * (hf) + 2) * 2048); CC_DSR128(dst[3], base, (4 * (hf) + 3) * 2048)
-#define CC_RD_B(dst, base, kq)                                                                             \
-  CC_DSR128(dst[0], base, (kq) * 16384 + 0); CC_DSR128(dst[1], base, (kq) * 16384 + 256);                  \
-  CC_DSR128(dst[2], base, (kq) * 16384 + 512); CC_DSR128(dst[3], base, (kq) * 16384 + 768)
-  for (int kt = 0; kt < KT; ++kt) {
-    const unsigned so = lds0 + stage * STAGE;
-    const unsigned va0 = so + a_lane0, va1 = so + a_lane1, vb = so + b_lane;
-    if (mode != W_IDLE) {
-      CC_RD_B(b0, vb, 0);
-      CC_RD_A(a0, va0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    if (kt + 1 < KT) issue(stage ^ 1);   // every wave is past the barrier behind its last read of that stage
-    __builtin_amdgcn_sched_barrier(0);
-    if (HALF && mode == W_HALF) {   // 64 rows of a half-height tile: row blocks 0-3 only, both k-chunks
-      CC_RD_B(b1, vb, 1);
-      CC_RD_A(a1, va1, 0);
-      CC_LGKM(8);
-      mfma_half(0, a0, b0);
-      CC_LGKM(0);
-      mfma_half(0, a1, b1);
-    } else if (!HALF && mode == W_FULL) {   // (W_IDLE: no rows of the tile — the wave only feeds the DMA and keeps the barriers)
-      CC_RD_A(a1, va0, 1);
-      CC_LGKM(4);
-      mfma_half(0, a0, b0);
-      CC_RD_B(b1, vb, 1);
-      CC_RD_A(a0, va1, 0);
-      CC_LGKM(8);
-      mfma_half(1, a1, b0);
-      CC_RD_A(a1, va1, 1);
-      CC_LGKM(4);
-      mfma_half(0, a0, b1);
-      CC_LGKM(0);
-      mfma_half(1, a1, b1);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    step_sync16();
-    stage ^= 1;
-  }
-#undef CC_RD_A
-#undef CC_RD_B
-}
-
-// ---- the one-plane K-segment as a ping-pong of the two wave groups (CC_G16_PP; the guide's "8-phase" structure) ----
+// ---- the one-plane K-segment as a ping-pong of the two wave groups (the guide's "8-phase" structure) ----
 // A K-step (64) is four phases of 16 MFMAs: (rows 0-63, k 0-31), (rows 64-127, k 0-31), (rows 0-63, k 32-63),
 // (rows 64-127, k 32-63) of the wave's 128 x 64 — the same MFMAs in the same order per accumulator as the other
 // segment forms.  Every phase is  [fragment reads + one 16 KiB DMA piece] s_barrier [lgkmcnt(0), 16 MFMAs] s_barrier,
@@ -345,18 +234,12 @@ __device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src,
   constexpr int STAGE = 65536, A_PLANE = 16384, B_OFF = 32768, B_HALF = 16384, A_STEP = 128, B_STEP = 32768;
   // one DMA piece = 16 KiB = two instructions per thread
   auto issue_a = [&](int step, int kq, int stage) {   // A k-half kq of K-step t + step
-#if defined(CC_PP_NODMA) || defined(CC_PP_NOA)
-    return;
-#endif
     char *dst = smem + stage * STAGE + kq * A_PLANE;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
       CC_GLDS16(src.a_cur[i] + (step * A_STEP + kq * 64) + src.a_voff[i], dst + (i * H_THREADS + wave * 64) * 16);
   };
   auto issue_b = [&](int step, int kq, int stage) {   // weight k-half kq of K-step t + step
-#if defined(CC_PP_NODMA) || defined(CC_PP_NOB)
-    return;
-#endif
     char *dst = smem + stage * STAGE + B_OFF + kq * B_HALF;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -366,17 +249,13 @@ __device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src,
   auto mfma16 = [&](int hf, const h8 (&af)[4], const h8 (&bf)[4]) {
     CC_LGKM(0);
     __builtin_amdgcn_sched_barrier(0);
-#ifndef CC_PP_NOPRIO
     __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         acc[4 * hf + mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[mt], bf[nt], acc[4 * hf + mt][nt], 0, 0, 0);
-#ifndef CC_PP_NOPRIO
     __builtin_amdgcn_s_setprio(0);
-#endif
     __builtin_amdgcn_sched_barrier(0);
   };
   auto bar = [&]() {
@@ -402,13 +281,6 @@ __device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src,
 #define CC_PP_B(dst, base, kq)                                                                               \
   CC_DSR128(dst[0], base, (kq) * 16384 + 0); CC_DSR128(dst[1], base, (kq) * 16384 + 256);                    \
   CC_DSR128(dst[2], base, (kq) * 16384 + 512); CC_DSR128(dst[3], base, (kq) * 16384 + 768)
-#ifdef CC_PP_NOREAD
-#undef CC_PP_A
-#undef CC_PP_B
-#define CC_PP_A(dst, base, kq, hf) asm volatile("" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]) : "v"(base))
-#define CC_PP_B(dst, base, kq) asm volatile("" : "+v"(dst[0]), "+v"(dst[1]), "+v"(dst[2]), "+v"(dst[3]) : "v"(base))
-  for (int i = 0; i < 4; ++i) { a0[i] = h8{}; a1[i] = h8{}; b[i] = h8{}; }
-#endif
   int stage = 0;
   for (int t = 0; t < KT; ++t) {
     const unsigned so = lds0 + stage * STAGE;
@@ -454,9 +326,7 @@ __device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src,
     bar();
     mfma16(1, a1, b);
     bar();
-#ifndef CC_PP_SAMEK
     src.a_cur[0] += A_STEP; src.a_cur[1] += A_STEP; src.b_cur += B_STEP;
-#endif
     stage ^= 1;
   }
   if (!wm) bar();   // waves 0-3 wait for the other group's last phase: every read of the stages is done
@@ -648,7 +518,7 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
     src.b_base = reinterpret_cast<const char *>(Wp + ((int64_t)n_tile * KTW + sg.wkt0) * (PLANES * TK * H_TN));
     src.b_voff = (unsigned)tid * 16u;
 
-    if constexpr (PLANES == 1 && !HALVES && CC_G16_PP) {
+    if constexpr (PLANES == 1 && !HALVES) {
       static_assert(C_::TK == 64 && C_::LDS == 131072, "ping-pong: K-step 64, two 64 KiB stages");
       SrcPP sp;
       const int prow = tid >> 2;                                   // row inside a 128-row block
@@ -666,15 +536,11 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
       const int prow_w = wm * 128 + r16;
       const int a_lane_pp = (prow_w * 4 + (q ^ swz16<4>(prow_w))) * 16;
       gemm16_segment_pp(acc, sp, KT, smem, a_lane_pp, b_off, wave, wm);
-    } else if constexpr (PLANES == 1 && C_::KQ == 2 && C_::NSTAGE == 2 && CC_G16_HANDWAIT) {
-      // the offsets of the other fragments are compile-time multiples: a row block further = 16 rows x 128 B
-      static_assert(CH == 8, "K-step 64: 8 chunks per row");
-      gemm16_segment_hand<HALVES>(acc, src, KT, smem, a_off[0][0], a_off[0][1], b_off, wave, mode);
-    } else {
-      if constexpr (PLANES == 2 && !HALVES && CC_G16_PP2) {
-        if (sg.nterms == 2) gemm16_segment_pp2(acc, src, KT, smem, a_off[0][0], b_off, wave, wm);
-        else gemm16_segment<PLANES, false, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
-      } else if (PLANES == 2 && sg.nterms == 2) gemm16_segment<PLANES, true, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
+    } else if constexpr (PLANES == 2 && !HALVES) {
+      if (sg.nterms == 2) gemm16_segment_pp2(acc, src, KT, smem, a_off[0][0], b_off, wave, wm);
+      else gemm16_segment<PLANES, false, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);   // A_lo x W_hi
+    } else {   // half-height tiles
+      if (PLANES == 2 && sg.nterms == 2) gemm16_segment<PLANES, true, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
       else gemm16_segment<PLANES, false, HALVES>(acc, src, KT, smem, a_off, b_off, wave, mode);
     }
   }
@@ -833,10 +699,7 @@ int launch_gemm16(const GemmSeg16 *segs, int nsegs, int64_t M, const PackedWeigh
   // workgroups per tile, 128 rows each, on twice the CUs (0.6 of a tile time) — in a second launch behind the whole
   // rounds.  (configs[4]'s N = 3300 is 13 column tiles, which no pass size turns into whole rounds.)
   const int64_t cus = num_cus();
-  int64_t tail = nwg % cus;
-#if !CC_G16_HALFTAIL
-  tail = cus;
-#endif
+  const int64_t tail = nwg % cus;
   // (not while a call alternates its passes between the two library streams: there the other stream's tiles fill the
   // partial round, and a second launch per product only delays them — a 12.5k-row shard step 4.3 -> 4.8 ms)
   const int64_t whole = (2 * tail <= cus && !two_streams_active()) ? nwg - tail : nwg;   // tiles of the full-height launch

@@ -2,8 +2,14 @@
 # GPU-box helper: rebuild gemm16 with different knobs, time the fp16 encoder layers.
 #   tools/gemm16_sweep.sh "<EXTRA flags of variant 1>" "<variant 2>" ...      ("" = the product build)
 # SWEEP_SHAPES: bench flag sets, ';'-separated (default: one 32768-row pass at C3's width, and configs[4]'s rank shape)
+# Variants with -DCC_G16_* / -DCC_PP_* flags need tools/experiments/g16_ablations.patch (SWEEP_PATCH=1 applies it for the
+# run; the product source has no build-time switches since round 4).
 set -u
 cd "$(dirname "$0")/.."
+if [ "${SWEEP_PATCH:-0}" = 1 ]; then
+  patch -p1 < tools/experiments/g16_ablations.patch || exit 1
+  trap 'patch -R -p1 < tools/experiments/g16_ablations.patch' EXIT
+fi
 shapes=${SWEEP_SHAPES:---cells 32768;--cells 62500 --genes 33000 --k 50}
 dtypes=${SWEEP_DTYPES:-f16 f16x2}
 for v in "$@"; do
