@@ -67,6 +67,11 @@ def parse():
     ap.add_argument('--dense-host', action='store_true', help='(default now; kept for old command lines)')
     ap.add_argument('--sparse', action='store_true', help='make the sparse first layer (fp32 over the non-zeros) the measured path')
     ap.add_argument('--no-profile', action='store_true', help='diagnostic: no HIP events in the timed region')
+    ap.add_argument('--native-comm', action='store_true',
+                    help='the exchange through the library itself (cc_knn_l2_sharded: RCCL bound by csrc/comm.cpp, no '
+                         'torch.distributed in the data path) instead of torch.distributed all_gather_into_tensor')
+    ap.add_argument('--no-parity-check', action='store_true',
+                    help='skip the parity evidence taken after the timed region (gathered rows re-encoded, sampled queries vs the oracle)')
     ap.add_argument('--cpu-sample-cells', type=int, default=8192)
     ap.add_argument('--cpu-sample-knn', type=int, default=40000)
     return ap.parse_args()
@@ -147,6 +152,51 @@ def cpu_baseline(args, enc, local, enc_host, alt_samples=None):
     }
 
 
+def parity_check(args, world, rank, enc, res, native, backend):
+    """Parity evidence of THIS run, taken after the timed region (never inside it), on every rank:
+    (1) the rank regenerates ONE other rank's block of cells (same generator, that rank's seed), encodes its first 256
+        rows itself and requires them bit-identical to those rows of the GATHERED encodings — the all-gather delivered
+        the other rank's bits to the right place (a row's encoding does not depend on the call it sits in);
+    (2) 32 of its own queries against oracle/knn_oracle.c on the gathered encodings: neighbour ids and distances
+        bit-exact, global numbering.
+    The oracle is the checker here, exactly as in tests/; nothing it computes is timed or reported as a result."""
+    import torch
+    from cellcomm_amd import pipeline, synth
+    from oracle import knn_oracle as ko
+    out = {'rank': rank, 'gathered_rows_bit_identical': False, 'knn_queries_bit_exact': 0, 'knn_queries_checked': 0}
+    lo, hi = pipeline.shard_bounds(args.cells, world, rank)
+    enc_all = res['encodings']
+    if enc_all is None:
+        # the fused exchange keeps the gathered rows inside the communicator: gather once more (cc_allgather_f32)
+        per = -(-args.cells // world)
+        gathered = torch.empty((world * per, args.latent), dtype=torch.float32, device='cuda')
+        torch.cuda.synchronize()
+        native.all_gather(res['enc_local'].data_ptr(), per * args.latent, gathered.data_ptr())
+        enc_all = gathered[:args.cells]
+    other = (rank + 1) % world
+    lo2, hi2 = pipeline.shard_bounds(args.cells, world, other)
+    rows = min(256, hi2 - lo2)
+    if rows > 0:
+        blk, _keep = synth.synth_csr_device(hi2 - lo2, args.genes, density=0.05, seed=1234 + other)
+        mine = torch.empty((rows, args.latent), dtype=torch.float32, device='cuda')
+        enc.predict_to_device(blk, mine.data_ptr(), 0, rows)
+        torch.cuda.synchronize()
+        out['gathered_rows_bit_identical'] = bool(torch.equal(mine, enc_all[lo2:lo2 + rows]))
+        out['rows_checked'], out['block_of_rank'] = rows, other
+        del blk, _keep
+    else:
+        out['gathered_rows_bit_identical'] = True
+    host_all = enc_all.cpu().numpy()
+    n_local = hi - lo
+    picks = np.random.default_rng(77 + rank).choice(n_local, min(32, n_local), replace=False) if n_local else []
+    good = 0
+    for q in picks:
+        wi, wd = ko.knn(host_all, args.k, q_begin=lo + int(q), n_q=1)
+        good += int(np.array_equal(res['idx'][q], wi[0]) and np.array_equal(res['dist'][q], wd[0]))
+    out['knn_queries_bit_exact'], out['knn_queries_checked'] = good, len(picks)
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` outside torchrun: start the N workers as a child process group.
     Nothing in this process has imported torch or touched HIP yet, and nothing will."""
@@ -157,6 +207,10 @@ def self_launch(args):
         port = sock.getsockname()[1]
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # HSA_ENABLE_IPC_MODE_LEGACY: inherited when the caller set it; otherwise 0 = dmabuf IPC.  The host driver of this
+    # pool supports only dmabuf handles: with the legacy mode RCCL's intra-node P2P set-up (hipIpcGetMemHandle) and any
+    # sharing of device tensors between processes fail with "invalid argument" (DESIGN.md §5).  Needed by the real
+    # RCCL path, not only by the one-device rehearsal.
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
@@ -216,8 +270,19 @@ def main():
 
     host_ms = {}   # host-clock milliseconds of this rank per stage, summed over the timed steps (pipeline `timings`)
 
+    native = None
+    if args.native_comm:
+        from cellcomm_amd import comm as cccomm
+        if world > 1 and os.environ.get('CC_BENCH_ONE_DEVICE'):
+            raise SystemExit('bench.py: --native-comm needs one GPU per rank (RCCL refuses two ranks on one device); '
+                             'the CC_BENCH_ONE_DEVICE rehearsal covers the torch.distributed exchange only')
+        native = cccomm.NativeComm.from_torch_distributed() if world > 1 else cccomm.NativeComm(1, 0, cccomm.make_unique_id())
+
     def step():
         # encodings reach pinned host memory on a side stream while the kNN search runs
+        if native is not None:
+            return pipeline.encode_and_knn_native(enc, local, args.k, native, args.cells, backend=backend,
+                                                  host_encodings=host_enc_t, timings=host_ms, fused=True)
         return pipeline.encode_and_knn(enc, local, args.k, backend=backend, host_encodings=host_enc_t,
                                        n_total=args.cells if world > 1 else None, timings=host_ms)
 
@@ -242,6 +307,31 @@ def main():
     _lib.profile_enable(False)
     main_host_ms = {k: v / args.steps for k, v in host_ms.items()}
     main_sample = host_enc.copy()   # the alt legs below reuse the pinned buffer
+    # parity evidence of this very run (outside the timed region; before the alt legs overwrite the pinned results)
+    parity = None
+    if not args.no_parity_check:
+        try:
+            mine_parity = parity_check(args, world, rank, enc, res, native, backend)
+        except Exception as err:    # a failing check must not leave the other ranks in a collective
+            mine_parity = {'rank': rank, 'gathered_rows_bit_identical': False, 'knn_queries_bit_exact': 0,
+                           'knn_queries_checked': -1, 'error': f'{type(err).__name__}: {err}'}
+        everyone_parity = [mine_parity]
+        if world > 1:
+            everyone_parity = [None] * world
+            dist.all_gather_object(everyone_parity, mine_parity)
+        parity = {'gathered_rows_bit_identical': all(p['gathered_rows_bit_identical'] for p in everyone_parity),
+                  'knn_queries_bit_exact': sum(p['knn_queries_bit_exact'] for p in everyone_parity),
+                  'knn_queries_checked': sum(max(p['knn_queries_checked'], 0) for p in everyone_parity),
+                  'ranks_checked': len(everyone_parity),
+                  'exchange': 'cc_knn_l2_sharded (RCCL via csrc/comm.cpp)' if native is not None else
+                              ('torch.distributed all_gather_into_tensor (%s)' % dist.get_backend() if world > 1 else 'none (one rank)'),
+                  'rows_checked_per_rank': 256, 'queries_per_rank': 32,
+                  'errors': [p['error'] for p in everyone_parity if 'error' in p],
+                  'note': 'taken after the timed region: every rank re-encodes the first rows of ANOTHER rank\'s block and '
+                          'compares them with the gathered encodings bit for bit, and checks 32 of its own queries against '
+                          'oracle/knn_oracle.c on the gathered encodings (ids and distances bit-exact)'}
+        parity['ok'] = bool(parity['gathered_rows_bit_identical'] and not parity['errors']
+                            and parity['knn_queries_bit_exact'] == parity['knn_queries_checked'])
     stages_by_rank = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=backend.collective_device)
@@ -436,11 +526,13 @@ def main():
                                    f'integer counts), {args.arch} encoder latent={args.latent} (random Glorot weights), '
                                    f'exact k={args.k} brute-force kNN',
                        'cells': args.cells, 'genes': args.genes, 'latent': args.latent, 'k': args.k,
-                       'arch': args.arch, 'parallelism': f'cells sharded over {world} GPU(s), 1 all-gather/step',
+                       'arch': args.arch, 'parallelism': f'cells sharded over {world} GPU(s), 1 all-gather/step' + (' (library exchange: cc_knn_l2_sharded)' if native is not None else ''),
                        'knn_fallback_queries_rank0': int(_lib.lib().cc_knn_last_fallback_count())},
             'roofline': roofline,
             'stages_rank0': stages,
         }
+        if parity is not None:
+            line['parity_check'] = parity
         if stages_by_rank is not None:
             line['stages_by_rank'] = stages_by_rank
             line['allgather_ms'] = stages_by_rank.get('host_allgather_ms')
@@ -490,9 +582,13 @@ def main():
                     alt_f16['max_rel_vs_f16_operand_oracle_sample'] = rel
             line['cpu_baseline'] = base
         print(json.dumps(line), flush=True)
+    if native is not None:
+        native.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if parity is not None and not parity['ok']:
+        raise SystemExit(f'bench.py rank {rank}: parity check FAILED: {json.dumps(parity)}')
 
 
 if __name__ == '__main__':

@@ -131,6 +131,8 @@ struct Encoder {
   int64_t fallback_passes = 0;
   int64_t w0 = 0, w1 = 0;  // hidden widths of the first two layers
   int64_t batch = 8192;
+  bool batch_user = false;   // cc_encoder_set_batch was called: the default below is not re-derived
+  int batch_gen = -1;        // init generation the default was derived for (the CU count is only known after cc_init)
   std::vector<WShape> shapes;
   std::vector<std::vector<float>> w;
   std::vector<bool> have;
@@ -169,7 +171,41 @@ static void encoder_shapes(Encoder *e) {
   e->have.assign(e->shapes.size(), false);
 }
 
+// Rows per pass.  GEMM time is quantised in rounds of resident tiles (fp32: 128 x 128, 3 per CU; fp16: 256 x 256, 1 per
+// CU), so the pass is the number of m-tiles whose layer-1 and layer-2 tile counts (weighted by their FLOP) fill whole
+// rounds best, searched from half to twice the default.  At G = 30000 the cont encoder keeps the defaults (8192 rows:
+// exactly 2 + 1 rounds; 32768 for the fp16 kernels: 6 + 3); the classify encoder (1000 columns = 8 n-tiles: 512 tiles
+// = 2/3 of a round at 8192 rows) takes 12288, configs[1]'s width (G = 20000) 12288, configs[4]'s (13 + 7 n-tiles) 65536.
+static int64_t default_pass_rows(const Encoder *e) {
+  const bool f32 = e->dtype == CC_DTYPE_F32;
+  const int64_t tm = f32 ? GEMM_BM : GEMM16_TILE, tn = f32 ? GEMM_BN : GEMM16_TILE;
+  const int64_t round = (f32 ? 3 : 1) * (int64_t)num_cus();
+  const int64_t def_mt = (f32 ? 8192 : 32768) / tm;
+  if (e->w0 <= 0 || e->w1 <= 0) return def_mt * tm;
+  const int64_t nt1 = ceil_div(e->w0, tn), nt2 = ceil_div(e->w1, tn);
+  const double f1 = (double)e->G * (double)e->w0;
+  const double f2 = (e->arch == CC_ARCH_CONT ? (double)(e->w0 + e->G) : (double)e->w0) * (double)e->w1;
+  auto fill = [&](int64_t tiles) { return (double)tiles / (double)(ceil_div(tiles, round) * round); };
+  auto eff = [&](int64_t mt) { return (f1 * fill(mt * nt1) + f2 * fill(mt * nt2)) / (f1 + f2); };
+  int64_t best = def_mt;
+  double best_eff = eff(def_mt) + 0.01;   // the default unless another size is worth more than 1 %
+  for (int64_t mt = def_mt / 2; mt <= 2 * def_mt; ++mt) {
+    const double v = eff(mt);
+    if (v > best_eff + 1e-9) { best = mt; best_eff = v; }
+  }
+  return best * tm;
+}
+
+// The default rows per pass depend on the CU count of the device, which cc_encoder_create may not know yet (it does not
+// require cc_init) and which changes with cc_shutdown + cc_init on another device: re-derived per init generation.
+static void encoder_refresh_batch(Encoder *e) {
+  if (e->batch_user || !initialised() || e->batch_gen == init_generation()) return;
+  e->batch = default_pass_rows(e);
+  e->batch_gen = init_generation();
+}
+
 static int encoder_pack(Encoder *e) {
+  encoder_refresh_batch(e);
   for (size_t i = 0; i < e->have.size(); ++i)
     if (!e->have[i]) {
       set_error("encoder weight %zu has not been set", i);
@@ -323,7 +359,7 @@ static int encode_csr_sparse(Encoder *e, Csr *c, int64_t row_start, int64_t n, f
   // workgroups at one workgroup per CU, then 1.15 rounds for layer 2): two halves, cut at a 256-row block, on the two
   // library streams, so that the CUs one half leaves idle in its last round run workgroups of the other half.
   const int64_t rb0 = row_start / SPMM_ROWS, nrb = ceil_div(end, SPMM_ROWS) - rb0;
-  const double rounds = (double)nrb * (double)e->S1.npan / 256.0;
+  const double rounds = (double)nrb * (double)e->S1.npan / (double)num_cus();
   if (n <= P && nrb >= 4 && rounds < 6.0) {
     int64_t mid = (rb0 + nrb / 2) * SPMM_ROWS;
     if (mid > row_start && mid < end) {
@@ -369,9 +405,12 @@ static int encoder_ensure_ws(Encoder *e, int64_t rows, int slots) {
     if (e->dtype != CC_DTYPE_F32) {
       e->ldxh = round_up(e->G, 64);
 #ifndef CC_NO_STRIDE_PAD
-      // a row stride within 8 KiB of a multiple of 64 KiB (G = 33000: 64.5 KiB) puts consecutive rows of an A tile on the
-      // same memory channels: layer 1 lost 2-5 % at configs[4]'s width.  One more 8 KiB of (never read) padding per row.
-      if ((e->ldxh * 2) % 65536 < 8192 || (e->ldxh * 2) % 65536 > 65536 - 8192) e->ldxh += 4096;
+      // a row stride within 8 KiB of a NON-ZERO multiple of 64 KiB puts consecutive rows of an A tile on the same memory
+      // channels: layer 1 lost 2-5 % at configs[4]'s width (G = 33000: 64.5 KiB) and at C3's (G = 30000: 58.6 KiB, measured
+      // with and without, round 3).  One more 8 KiB of padding per row, which the gather neither writes nor the GEMM
+      // reads (the K loop stops at round_up(G, 64)).  Strides below 56 KiB (small gene sets) are left alone.
+      const int64_t stride_b = e->ldxh * 2, rem_b = stride_b % 65536;
+      if (stride_b >= 65536 - 8192 && (rem_b < 8192 || rem_b > 65536 - 8192)) e->ldxh += 4096;
 #endif
       e->ld1h = e->w0 == 0 ? 64 : round_up(e->w0, 64);
       const size_t bx = sizeof(_Float16) * (size_t)(rows * e->ldxh), b1 = sizeof(_Float16) * (size_t)(rows * e->ld1h);
@@ -473,6 +512,7 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   CC_REQUIRE(c->G == e->G, "matrix has %d genes, encoder expects %d", c->G, e->G);
   int rc;
   if ((rc = check_rows(c, row_ids, row_start, n))) return rc;
+  encoder_refresh_batch(e);
   if (e->dirty && (rc = encoder_pack(e))) return rc;
   if (!nested) e->fallback_passes = 0;
   if (n == 0) return CC_OK;
@@ -525,7 +565,10 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
     for (int64_t i = 0; off < n; ++i, off += each) plan.push_back({off, (n - off < each) ? n - off : each, (int)(i & 1)});
     if (each > B || npass == 1) B = each;
   } else if (e->dtype != CC_DTYPE_F32 && npass == 1 && n >= 2 * GEMM16_TILE &&
-             (double)ceil_div(n, GEMM16_TILE) * (double)e->L16[0].NT < 4.0 * 256.0) {
+             (double)ceil_div(n, GEMM16_TILE) * (double)e->L16[0].NT >= (double)num_cus() &&
+             (double)ceil_div(n, GEMM16_TILE) * (double)e->L16[0].NT < 4.0 * (double)num_cus()) {
+    // (at least one whole round of layer-1 tiles: a 512-4096-row minibatch at a small gene set is a handful of tiles,
+    // which the half-height tail kernel of launch_gemm16 serves better than two streams with two gathers each)
     // fp16 kernels, one short pass (a rank's shard at 4-8 GPUs: 12.5k rows are 588 layer-1 tiles = 2.3 rounds at one
     // 256 x 256 tile per CU, then 1.15 rounds of layer 2): two halves on the two streams fill each other's last rounds
     // (x1.15-1.2 on the shard step).  Longer calls run whole rounds per pass and lose with a second stream (round 2:
@@ -672,31 +715,6 @@ int cc_synchronize(void) {
 }
 
 // ---- encoder -----------------------------------------------------------------------
-// Rows per pass.  GEMM time is quantised in rounds of resident tiles (fp32: 128 x 128, 3 per CU; fp16: 256 x 256, 1 per
-// CU), so the pass is the number of m-tiles whose layer-1 and layer-2 tile counts (weighted by their FLOP) fill whole
-// rounds best, searched from half to twice the default.  At G = 30000 the cont encoder keeps the defaults (8192 rows:
-// exactly 2 + 1 rounds; 32768 for the fp16 kernels: 6 + 3); the classify encoder (1000 columns = 8 n-tiles: 512 tiles
-// = 2/3 of a round at 8192 rows) takes 12288, configs[1]'s width (G = 20000) 12288, configs[4]'s (13 + 7 n-tiles) 65536.
-static int64_t default_pass_rows(const Encoder *e) {
-  const bool f32 = e->dtype == CC_DTYPE_F32;
-  const int64_t tm = f32 ? GEMM_BM : GEMM16_TILE, tn = f32 ? GEMM_BN : GEMM16_TILE;
-  const int64_t round = (f32 ? 3 : 1) * (int64_t)num_cus();
-  const int64_t def_mt = (f32 ? 8192 : 32768) / tm;
-  if (e->w0 <= 0 || e->w1 <= 0) return def_mt * tm;
-  const int64_t nt1 = ceil_div(e->w0, tn), nt2 = ceil_div(e->w1, tn);
-  const double f1 = (double)e->G * (double)e->w0;
-  const double f2 = (e->arch == CC_ARCH_CONT ? (double)(e->w0 + e->G) : (double)e->w0) * (double)e->w1;
-  auto fill = [&](int64_t tiles) { return (double)tiles / (double)(ceil_div(tiles, round) * round); };
-  auto eff = [&](int64_t mt) { return (f1 * fill(mt * nt1) + f2 * fill(mt * nt2)) / (f1 + f2); };
-  int64_t best = def_mt;
-  double best_eff = eff(def_mt) + 0.01;   // the default unless another size is worth more than 1 %
-  for (int64_t mt = def_mt / 2; mt <= 2 * def_mt; ++mt) {
-    const double v = eff(mt);
-    if (v > best_eff + 1e-9) { best = mt; best_eff = v; }
-  }
-  return best * tm;
-}
-
 int cc_encoder_create(int arch, int G, int E, int dtype, void **enc) {
   CC_REQUIRE(enc != nullptr, "enc is NULL");
   CC_REQUIRE(arch == CC_ARCH_CONT || arch == CC_ARCH_CLS, "unknown encoder arch %d", arch);
@@ -706,6 +724,7 @@ int cc_encoder_create(int arch, int G, int E, int dtype, void **enc) {
   e->arch = arch; e->G = G; e->E = E; e->dtype = dtype;
   encoder_shapes(e);
   e->batch = default_pass_rows(e);
+  e->batch_gen = initialised() ? init_generation() : -1;
   *enc = e;
   return CC_OK;
 }
@@ -777,6 +796,7 @@ int64_t cc_encoder_fp32_fallback_passes(void *enc) {
 
 int64_t cc_encoder_batch(void *enc) {
   if (!enc) { set_error("encoder handle is NULL"); return -1; }
+  encoder_refresh_batch(static_cast<Encoder *>(enc));
   return static_cast<Encoder *>(enc)->batch;
 }
 
@@ -784,6 +804,7 @@ int cc_encoder_set_batch(void *enc, int64_t batch_rows) {
   CC_HANDLE(enc, "encoder");
   CC_REQUIRE(batch_rows >= 1, "batch_rows must be >= 1");
   static_cast<Encoder *>(enc)->batch = batch_rows;
+  static_cast<Encoder *>(enc)->batch_user = true;
   return CC_OK;
 }
 
@@ -907,6 +928,7 @@ int cc_encode_dense(void *enc, const float *host_x, int64_t n, float *host_out) 
   CC_REQUIRE(n >= 0, "negative row count");
   CC_REQUIRE((host_x != nullptr && host_out != nullptr) || n == 0, "host_x / host_out is NULL");
   int rc;
+  encoder_refresh_batch(e);
   if (e->dirty && (rc = encoder_pack(e))) return rc;
   e->fallback_passes = 0;
   if (n == 0) return CC_OK;

@@ -8,7 +8,29 @@
 // 128-byte unique id that rank 0 makes (cc_comm_unique_id) and the host program distributes
 // (file, env, MPI, torch.distributed store ...).
 #include <dlfcn.h>
-#include <rccl/rccl.h>   // types and prototypes only: nothing here links against librccl, the entry points come from dlsym
+// Types and prototypes only: nothing here links against librccl, the entry points come from dlsym.  With the ROCm
+// header present (the normal case; `make RCCL_INC=-I<dir>` for another location) the function-pointer types below are
+// the header's own prototypes; without it the library still builds from the five declarations of the stable NCCL 2
+// ABI restated here (the static_asserts then only check this file against itself).
+#if __has_include(<rccl/rccl.h>)
+#include <rccl/rccl.h>
+#else
+#include <hip/hip_runtime_api.h>
+#include <cstddef>
+extern "C" {
+#define NCCL_UNIQUE_ID_BYTES 128
+typedef struct { char internal[NCCL_UNIQUE_ID_BYTES]; } ncclUniqueId;
+typedef struct ncclComm *ncclComm_t;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclFloat32 = 7 } ncclDataType_t;
+ncclResult_t ncclGetUniqueId(ncclUniqueId *uniqueId);
+ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId commId, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t comm);
+ncclResult_t ncclAllGather(const void *sendbuff, void *recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t comm,
+                           hipStream_t stream);
+const char *ncclGetErrorString(ncclResult_t result);
+}
+#endif
 
 #include <cstdlib>
 

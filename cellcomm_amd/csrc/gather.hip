@@ -94,7 +94,7 @@ __device__ __forceinline__ void raise_fp16_flags(int bad, int *flags) {
 __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_f16_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ vals, const int32_t *__restrict__ chunk_rel, int nc1,
-    const int64_t *__restrict__ row_ids, int64_t row_start, int nchunks, int64_t ld,
+    const int64_t *__restrict__ row_ids, int64_t row_start, int nchunks, int64_t ld, int64_t wcols,
     _Float16 *__restrict__ out, int *__restrict__ inexact) {
   // TWO index chunks (8192 columns) per workgroup, staged as fp16: the same 16 KiB of LDS and of output per workgroup as
   // the fp32 kernel (one chunk per workgroup wrote 8 KiB and ran at half its byte rate: 3.2 against 6.1 TB/s)
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_f16_kernel(
   const int chunk = 2 * (int)(blockIdx.x % nchunks);
   const int64_t row = row_ids ? row_ids[r] : row_start + r;
   const int64_t c0 = (int64_t)chunk * GATHER_CH;
-  const int64_t c1 = (c0 + CH < ld) ? c0 + CH : ld;
+  const int64_t c1 = (c0 + CH < wcols) ? c0 + CH : wcols;   // columns [G, wcols) are zero-filled; [wcols, ld) stay untouched
   const int64_t beg = indptr[row];
   const int32_t *rel = chunk_rel + row * nc1;
   const int64_t lo = beg + rel[chunk < nc1 - 1 ? chunk : nc1 - 1];
@@ -235,13 +235,16 @@ int launch_gather_f16(const int64_t *d_indptr, const int32_t *d_indices, const f
                       int64_t ld, void *d_out_half, int *d_inexact, double nnz_hint) {
   if (n == 0) return CC_OK;
   CC_REQUIRE(ld % 8 == 0 && ld >= G, "gather: ld=%lld must be a multiple of 8 and >= G=%d", (long long)ld, G);
-  const int nchunks = (int)ceil_div(ld, 2 * GATHER_CH);   // two index chunks per workgroup
+  // the columns the GEMM reads: G rounded up to its K-step; a row stride beyond that (the 8 KiB pad that keeps fp16 row
+  // strides away from multiples of 64 KiB, api.hip) is neither written here nor read there
+  const int64_t wcols = round_up(G, 64) < ld ? round_up(G, 64) : ld;
+  const int nchunks = (int)ceil_div(wcols, 2 * GATHER_CH);   // two index chunks per workgroup
   const int nc1 = gather_chunk_count(G);
   const int64_t nblocks = n * nchunks;
   CC_REQUIRE(nblocks < (int64_t)2147483647, "gather: grid too large (%lld blocks)", (long long)nblocks);
-  ProfScope prof(CC_PROF_GATHER, 8.0 * nnz_hint + 8.0 * (double)n + 2.0 * (double)ld * (double)n);
+  ProfScope prof(CC_PROF_GATHER, 8.0 * nnz_hint + 8.0 * (double)n + 2.0 * (double)wcols * (double)n);
   hipLaunchKernelGGL(csr_gather_f16_kernel, dim3((unsigned)nblocks), dim3(GATHER_THREADS), 0, stream(), d_indptr,
-                     d_indices, d_vals, d_chunk_rel, nc1, d_row_ids, row_start, nchunks, ld,
+                     d_indices, d_vals, d_chunk_rel, nc1, d_row_ids, row_start, nchunks, ld, wcols,
                      static_cast<_Float16 *>(d_out_half), d_inexact);
   CC_HIP(hipGetLastError());
   return CC_OK;

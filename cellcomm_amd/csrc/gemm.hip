@@ -53,7 +53,8 @@ constexpr int GEMM_THREADS = 256;
 constexpr int TILE_W_FLOAT4 = (BK / 4) * BN;    // float4 per packed W tile
 constexpr int A_F4_PER_ROW = BK / 4;            // float4 per A-tile row
 constexpr int A_ROWS_PER_PASS = GEMM_THREADS / A_F4_PER_ROW;
-constexpr int NA = BM / A_ROWS_PER_PASS;        // A float4 staged per thread
+constexpr int NA = BM / A_ROWS_PER_PASS;        // A float4 staged per thread (128-row tile)
+constexpr int NA_HALF = NA / 2;                 // ... of a half-height (64-row) tile
 constexpr int NB = TILE_W_FLOAT4 / GEMM_THREADS;  // W float4 staged per thread
 #ifndef CC_GEMM_GROUP_M
 #define CC_GEMM_GROUP_M 8
@@ -68,9 +69,9 @@ __device__ __forceinline__ float sigmoidf_(float z) { return 1.0f / (1.0f + expf
 // column of the last n-tile all padding, 1/48 of layer 1's MFMAs).  A second instantiation of this loop in
 // the kernel made the allocator spill (336 B scratch), and a staging-only path for all-padding waves,
 // which compiles cleanly, gains nothing: the workgroup still runs at the pace of its three full waves.
-template <int KCLASS, int MTV, int NTV>
-__device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA], f32x4 (&rb)[NB], const float *(&pa)[NA],
-                                            const f32x4 *&wt, const int (&a_lr)[NA], const float *__restrict__ A2,
+template <int KCLASS, int MTV, int NTV, int NAV>
+__device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NAV], f32x4 (&rb)[NB], const float *(&pa)[NAV],
+                                            const f32x4 *&wt, const int (&a_lr)[NAV], const float *__restrict__ A2,
                                             int64_t m0, int64_t lda2, int KT1, int KT, float *As, f32x4 *Bs4,
                                             const float *a_lds, const f32x4 *b_lds, int tid, int a_row, int a_k4) {
   for (int kt = 0; kt < KT; ++kt) {
@@ -79,10 +80,10 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA]
       if (kt + 1 == KT1) {  // first tile of segment 2: re-base the A pointers (once per kernel)
         const float *base = A2 + m0 * lda2;
 #pragma unroll
-        for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * (int)lda2 + 4 * a_k4;
+        for (int p = 0; p < NAV; ++p) pa[p] = base + a_lr[p] * (int)lda2 + 4 * a_k4;
       }
 #pragma unroll
-      for (int p = 0; p < NA; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
+      for (int p = 0; p < NAV; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
 #pragma unroll
       for (int p = 0; p < NB; ++p) rb[p] = wt[p * GEMM_THREADS];
       wt += TILE_W_FLOAT4;
@@ -116,7 +117,7 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA]
     if (more) {
       float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;
 #pragma unroll
-      for (int p = 0; p < NA; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
+      for (int p = 0; p < NAV; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
 #pragma unroll
       for (int p = 0; p < NB; ++p) Bs4[tid + p * GEMM_THREADS] = rb[p];
     }
@@ -125,7 +126,11 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NA]
 }
 
 // KCLASS only names the instantiation (so profilers tell layer 1 / layer 2 / tail apart).
-template <int KCLASS>
+// HALF: half-height tiles.  Every 128 x 128 tile of the launch is worked by TWO workgroups, each on 64 of its rows
+// (4 waves as 2 x 2 of 32 x 64: one row of MFMA blocks per wave instead of two; the W tile and the K loop unchanged),
+// which is how a last round of tiles that is at most half full runs on twice the slots (launch_gemm): an output
+// element's sum is the same sequence of v_mfma_f32_32x32x2_f32 steps either way, so results are bit-identical.
+template <int KCLASS, bool HALF>
 __global__
 #if CC_GEMM_MINWAVES > 0
 __launch_bounds__(GEMM_THREADS, CC_GEMM_MINWAVES)
@@ -135,23 +140,26 @@ __launch_bounds__(GEMM_THREADS)
 void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const float *__restrict__ A2,
                           int64_t lda2, int64_t M, const f32x4 *__restrict__ Wp,
                           const float *__restrict__ bias, int KT1, int KT, int N, int MT, int NT,
-                          float *__restrict__ C, int64_t ldc, int act) {
-  constexpr int STAGE_FLOATS = BM * LDS_A_STRIDE + TILE_W_FLOAT4 * 4;
+                          float *__restrict__ C, int64_t ldc, int act, int tile0) {
+  constexpr int TM = HALF ? BM / 2 : BM;            // rows of this workgroup
+  constexpr int NAV = HALF ? NA_HALF : NA, MTV = HALF ? 1 : 2;
+  constexpr int STAGE_FLOATS = TM * LDS_A_STRIDE + TILE_W_FLOAT4 * 4;
   __shared__ __attribute__((aligned(16))) float lds[STAGE_FLOATS];
   float *As = lds;
-  f32x4 *Bs4 = reinterpret_cast<f32x4 *>(lds + BM * LDS_A_STRIDE);
+  f32x4 *Bs4 = reinterpret_cast<f32x4 *>(lds + TM * LDS_A_STRIDE);
 
-  // ---- workgroup → tile ---------------------------------------------------
-  const int nwg = MT * NT;
-  const int bid = blockIdx.x;
+  // ---- workgroup → tile: the launch covers tiles tile0 .. tile0 + nwg - 1 of the grouped order ----------------
+  const int nwg = HALF ? (int)(gridDim.x >> 1) : (int)gridDim.x;
+  const int bid = HALF ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
   const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
-  const int wgid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+  const int wgid = tile0 + (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
   const int per_group = GROUP_M * NT;
   const int first_m = (wgid / per_group) * GROUP_M;
   const int gsz = (MT - first_m < GROUP_M) ? MT - first_m : GROUP_M;
   const int m_tile = first_m + (wgid % per_group) % gsz;
   const int n_tile = (wgid % per_group) / gsz;
-  const int64_t m0 = (int64_t)m_tile * BM;
+  const int64_t m0 = (int64_t)m_tile * BM + (HALF ? (int64_t)(blockIdx.x & 1) * TM : 0);
+  if (HALF && m0 >= M) return;                      // the lower half of a tile that has <= 64 rows
   const int n0 = n_tile * BN;
 
   const int tid = threadIdx.x;
@@ -163,18 +171,18 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   //      segment switch) and a scalar running pointer into the packed W tiles ----
   const int a_row = tid / A_F4_PER_ROW;  // + A_ROWS_PER_PASS · p
   const int a_k4 = tid % A_F4_PER_ROW;
-  int a_lr[NA];
+  int a_lr[NAV];
 #pragma unroll
-  for (int p = 0; p < NA; ++p) {
+  for (int p = 0; p < NAV; ++p) {
     const int64_t gr = m0 + a_row + A_ROWS_PER_PASS * p;
     a_lr[p] = (int)((gr < M ? gr : M - 1) - m0);  // clamp the M tail onto a valid row
   }
-  const float *pa[NA];
+  const float *pa[NAV];
   {
     const float *base = KT1 > 0 ? A1 + m0 * lda1 : A2 + m0 * lda2;
     const int lda = (int)(KT1 > 0 ? lda1 : lda2);
 #pragma unroll
-    for (int p = 0; p < NA; ++p) pa[p] = base + a_lr[p] * lda + 4 * a_k4;
+    for (int p = 0; p < NAV; ++p) pa[p] = base + a_lr[p] * lda + 4 * a_k4;
   }
   const f32x4 *wt = Wp + (int64_t)n_tile * KT * TILE_W_FLOAT4 + tid;
 
@@ -187,7 +195,7 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
   // the accumulators are pinned below (any 16-aligned VGPR placement measured the same; AGPRs were
   // slower: the 84/84 register split spills).  The fp16 and kNN kernels did not react to the same pin
   // (tools/pin_sweep.sh).
-  f32x4 ra[NA], rb[NB];
+  f32x4 ra[NAV], rb[NB];
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -197,29 +205,35 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
   // pin the four accumulator tuples where the fast build has them (see the note above)
-  asm volatile("" : "+{v[0:15]}"(acc[1][1]));
-  asm volatile("" : "+{v[16:31]}"(acc[0][1]));
-  asm volatile("" : "+{v[32:47]}"(acc[1][0]));
-  asm volatile("" : "+{v[48:63]}"(acc[0][0]));
+  if (!HALF) {
+    asm volatile("" : "+{v[0:15]}"(acc[1][1]));
+    asm volatile("" : "+{v[16:31]}"(acc[0][1]));
+    asm volatile("" : "+{v[32:47]}"(acc[1][0]));
+    asm volatile("" : "+{v[48:63]}"(acc[0][0]));
+  } else {
+    asm volatile("" : "+{v[0:15]}"(acc[0][1]));
+    asm volatile("" : "+{v[16:31]}"(acc[0][0]));
+  }
 
   if (KT > 0) {
 #pragma unroll
-    for (int p = 0; p < NA; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
+    for (int p = 0; p < NAV; ++p) { ra[p] = *reinterpret_cast<const f32x4 *>(pa[p]); pa[p] += BK; }
 #pragma unroll
     for (int p = 0; p < NB; ++p) rb[p] = wt[p * GEMM_THREADS];
     wt += TILE_W_FLOAT4;
     float *aw = As + a_row * LDS_A_STRIDE + 4 * a_k4;
 #pragma unroll
-    for (int p = 0; p < NA; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
+    for (int p = 0; p < NAV; ++p) *reinterpret_cast<f32x4 *>(aw + p * A_ROWS_PER_PASS * LDS_A_STRIDE) = ra[p];
 #pragma unroll
     for (int p = 0; p < NB; ++p) Bs4[tid + p * GEMM_THREADS] = rb[p];
   }
   __syncthreads();
 
-  const float *a_lds = As + (wm * 64 + r) * LDS_A_STRIDE + 4 * h;
+  constexpr int WROWS = 32 * MTV;                   // rows of a wave: 64 (two MFMA block rows) or 32
+  const float *a_lds = As + (wm * WROWS + r) * LDS_A_STRIDE + 4 * h;
   const f32x4 *b_lds = Bs4 + h * BN + wn * 64 + r;
 
-  gemm_k_loop<KCLASS, 2, 2>(acc, ra, rb, pa, wt, a_lr, A2, m0, lda2, KT1, KT, As, Bs4, a_lds, b_lds, tid, a_row, a_k4);
+  gemm_k_loop<KCLASS, MTV, 2, NAV>(acc, ra, rb, pa, wt, a_lr, A2, m0, lda2, KT1, KT, As, Bs4, a_lds, b_lds, tid, a_row, a_k4);
 
   // ---- epilogue: bias + activation, 128-byte row segments per half-wave ------
 #pragma unroll
@@ -228,10 +242,10 @@ void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const floa
     const bool col_ok = col < N;
     const float bcol = col_ok ? bias[col] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MTV; ++mt) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const int64_t row = m0 + wm * 64 + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int64_t row = m0 + wm * WROWS + mt * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (col_ok && row < M) {
           float z = acc[mt][nt][e] + bcol;
           C[row * ldc + col] = (act == ACT_SIGMOID) ? sigmoidf_(z) : (act == ACT_RELU ? fmaxf(z, 0.f) : z);
@@ -321,13 +335,28 @@ int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, in
   const int64_t nwg = MT * W.NT;
   CC_REQUIRE(nwg < (int64_t)2147483647, "gemm: grid too large");
   ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
-#define CC_LAUNCH_GEMM(KC)                                                                                  \
-  hipLaunchKernelGGL(gemm_bias_act_kernel<KC>, dim3((unsigned)nwg), dim3(GEMM_THREADS), 0, stream(), A1,    \
-                     lda1, A2, lda2, M, reinterpret_cast<const f32x4 *>(W.d_w), W.d_bias, (int)W.KT1,     \
-                     (int)(W.KT1 + W.KT2), (int)W.N, (int)MT, (int)W.NT, C, ldc, act)
-  if (prof_class == CC_PROF_GEMM_L1) CC_LAUNCH_GEMM(1);
-  else if (prof_class == CC_PROF_GEMM_L2) CC_LAUNCH_GEMM(2);
-  else CC_LAUNCH_GEMM(3);
+  // Three workgroups per CU: the product runs in rounds of 3 x CUs tiles and its last round costs a whole tile time
+  // however few tiles it holds.  A last round that is at most half full runs as half-height tiles instead — two
+  // workgroups per tile, 64 rows each, on twice the slots — in a second launch behind the whole rounds (round 4, as
+  // the fp16 kernels since round 3).  C3's 8192-row passes are whole rounds (24 / 12 column tiles x 64 = 2 / 1 rounds)
+  // and never take it; configs[1] (1264 tiles = 1.65 rounds), a 12.5k-row shard (3.06 rounds) and every call of a
+  // few rows do.  A row's sums are the same MFMAs in the same order either way: results do not change.
+  const int64_t slots = (CC_GEMM_MINWAVES > 0 ? CC_GEMM_MINWAVES : 3) * (int64_t)num_cus();
+  const int64_t tail = nwg % slots;
+  const int64_t whole = (tail > 0 && 2 * tail <= slots) ? nwg - tail : nwg;   // tiles of the full-height launch
+#define CC_LAUNCH_GEMM(KC, HV, GRID, TILE0)                                                                          \
+  hipLaunchKernelGGL((gemm_bias_act_kernel<KC, HV>), dim3((unsigned)(GRID)), dim3(GEMM_THREADS), 0, stream(), A1,    \
+                     lda1, A2, lda2, M, reinterpret_cast<const f32x4 *>(W.d_w), W.d_bias, (int)W.KT1,              \
+                     (int)(W.KT1 + W.KT2), (int)W.N, (int)MT, (int)W.NT, C, ldc, act, (int)(TILE0))
+#define CC_LAUNCH_GEMM_CLASS(HV, GRID, TILE0)                                \
+  do {                                                                      \
+    if (prof_class == CC_PROF_GEMM_L1) CC_LAUNCH_GEMM(1, HV, GRID, TILE0);  \
+    else if (prof_class == CC_PROF_GEMM_L2) CC_LAUNCH_GEMM(2, HV, GRID, TILE0); \
+    else CC_LAUNCH_GEMM(3, HV, GRID, TILE0);                                \
+  } while (0)
+  if (whole > 0) CC_LAUNCH_GEMM_CLASS(false, whole, 0);
+  if (whole < nwg) CC_LAUNCH_GEMM_CLASS(true, 2 * (nwg - whole), whole);
+#undef CC_LAUNCH_GEMM_CLASS
 #undef CC_LAUNCH_GEMM
   CC_HIP(hipGetLastError());
   return CC_OK;

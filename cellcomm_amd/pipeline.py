@@ -62,19 +62,36 @@ class HipBackend:
         # wait for the copy of the encodings to host memory that `copy_out` started on its side stream, which is meant
         # to run underneath the search (round 3: 1.7 ms of the 209 ms step)
         self.torch.cuda.current_stream().synchronize()
+        return knn_graph_device(enc_all.data_ptr(), n_total, enc_all.shape[1], k, q_begin, n_q, include_self,
+                                out=self.result_buffers(n_q, k))
+
+    def result_buffers(self, n_q, k):
+        """Pinned host arrays for the neighbour ids and distances of a search, reused across calls."""
         key = (n_q, k)
-        if self._out_key != key:                # pinned host result buffers, reused across calls
+        if self._out_key != key:
             self._out = (self.torch.empty(key, dtype=self.torch.int32, pin_memory=True),
                          self.torch.empty(key, dtype=self.torch.float32, pin_memory=True))
             self._out_key = key
-        out = (self._out[0].numpy(), self._out[1].numpy())
-        return knn_graph_device(enc_all.data_ptr(), n_total, enc_all.shape[1], k, q_begin, n_q, include_self, out=out)
+        return self._out[0].numpy(), self._out[1].numpy()
 
 
-def encode_and_knn_native(encoder, local_matrix, k, comm, n_total, include_self=False, backend=None):
+def encode_and_knn_native(encoder, local_matrix, k, comm, n_total, include_self=False, backend=None, host_encodings=None,
+                          timings=None, fused=False):
     """The same path with the exchange done by the library itself (`comm.NativeComm`: RCCL through the C ABI,
     no torch.distributed in the data path).  `local_matrix` must be block `shard_bounds(n_total, comm.world_size,
-    comm.rank)` of the global matrix.  Returns the same dict as `encode_and_knn`."""
+    comm.rank)` of the global matrix.  Returns the same dict as `encode_and_knn` plus `enc_local` (this rank's block,
+    padded to ceil(n_total / world) rows).
+
+    `fused=False`: `cc_allgather_f32` into a buffer of the caller, then the search (`cc_knn_l2_dev`).
+    `fused=True`: ONE library call does both (`cc_knn_l2_sharded`, csrc/comm.cpp — what a non-Python host calls); the
+    gathered encodings then stay inside the communicator and `encodings` is None.
+    `host_encodings` / `timings`: as in `encode_and_knn` (`allgather_ms` is part of `knn_ms` when fused)."""
+    import time
+    clock = time.perf_counter
+
+    def tick(key, t_start):
+        if timings is not None:
+            timings[key] = timings.get(key, 0.0) + (clock() - t_start) * 1e3
     backend = backend or HipBackend()
     lo, hi = shard_bounds(n_total, comm.world_size, comm.rank)
     n_local = local_matrix.shape[0]
@@ -86,12 +103,29 @@ def encode_and_knn_native(encoder, local_matrix, k, comm, n_total, include_self=
     if n_local < per:
         enc_local[n_local:].zero_()
         backend.torch.cuda.synchronize()
+    t0 = clock()
     backend.encode_into(encoder, local_matrix, enc_local)
-    gathered = backend.alloc(comm.world_size * per, width)
-    comm.all_gather(enc_local.data_ptr(), per * width, gathered.data_ptr())     # the one collective
-    enc_all = gathered[:n_total]
-    idx, dst = backend.knn(enc_all, n_total, lo, n_local, k, include_self)
-    return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=lo, n_total=n_total)
+    tick('encode_ms', t0)
+    done = backend.copy_out(enc_local[:n_local], host_encodings) if host_encodings is not None else None
+    if fused:
+        t0 = clock()
+        idx, dst = comm.knn_sharded(enc_local.data_ptr(), n_local, n_total, width, k, include_self,
+                                    out=backend.result_buffers(n_local, k))
+        tick('knn_ms', t0)
+        enc_all = None
+    else:
+        gathered = backend.alloc(comm.world_size * per, width)
+        backend.torch.cuda.current_stream().synchronize()
+        t0 = clock()
+        comm.all_gather(enc_local.data_ptr(), per * width, gathered.data_ptr())     # the one collective
+        tick('allgather_ms', t0)
+        enc_all = gathered[:n_total]
+        t0 = clock()
+        idx, dst = backend.knn(enc_all, n_total, lo, n_local, k, include_self)
+        tick('knn_ms', t0)
+    if done is not None:
+        done()
+    return dict(encodings=enc_all, idx=idx, dist=dst, q_begin=lo, n_total=n_total, enc_local=enc_local)
 
 
 def encode_and_knn(encoder, local_matrix, k, include_self=False, backend=None, group=None, host_encodings=None,

@@ -143,6 +143,30 @@ def test_bench_gpus_2_self_launch_on_one_device(hip):
     assert {'gather', 'gemm_l1', 'host_encode_ms', 'host_allgather_ms', 'host_knn_ms'} <= set(by_rank)
     assert all(v['max'] >= v['min'] >= 0 and 0 <= v['argmax_rank'] < 2 for v in by_rank.values())
     assert res['allgather_ms'] == by_rank['host_allgather_ms']
+    # parity evidence of the run itself: each rank re-encoded the first 256 rows of the OTHER rank's
+    # block and found them bit-identical in the gathered encodings; 32 queries per rank bit-exact against the oracle
+    pc = res['parity_check']
+    assert pc['ok'] and pc['gathered_rows_bit_identical'] and pc['ranks_checked'] == 2 and not pc['errors']
+    assert pc['knn_queries_bit_exact'] == pc['knn_queries_checked'] == 64
+    assert 'gloo' in pc['exchange']
+
+
+@pytest.mark.gpu
+def test_bench_native_comm_one_rank(hip):
+    """`--native-comm`: the exchange through cc_knn_l2_sharded (RCCL bound by the library).  A one-GPU box can host one
+    rank only (RCCL refuses two ranks on one device); the two-rank rehearsal flag is refused with a reason."""
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'CC_BENCH_ONE_DEVICE')}
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '2', '--warmup', '1', '--cells', '6000', '--genes', '2000',
+           '--latent', '32', '--no-cpu-baseline', '--no-alt', '--native-comm']
+    proc = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stdout[-2000:] + proc.stderr[-4000:]
+    res = json.loads([ln for ln in proc.stdout.splitlines() if ln.startswith('{')][-1])
+    pc = res['parity_check']
+    assert pc['ok'] and pc['knn_queries_bit_exact'] == 32 and 'cc_knn_l2_sharded' in pc['exchange']
+    assert 'cc_knn_l2_sharded' in res['config']['parallelism'] and res['value'] > 0
+    env.update(CC_BENCH_ONE_DEVICE='1')
+    proc = subprocess.run(cmd + ['--gpus', '2'], capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode != 0 and 'needs one GPU per rank' in proc.stderr
 
 
 @pytest.mark.gpu

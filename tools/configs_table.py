@@ -27,6 +27,11 @@ BENCH_ROWS = [
     ("configs[3]: one rank's 125k of 1M cells (encode + kNN among its own rows)", ['--cells', '125000']),
     ("configs[4]: one rank's 62.5k of 500k x 33k cells, fp16 operands, k = 50 (encode + kNN among its own rows)",
      ['--cells', '62500', '--genes', '33000', '--k', '50', '--dtype', 'f16']),
+    # the two 8-GPU configs at FULL size on ONE GPU: the N = 1 denominators of their ">= 6x at 8 GPUs" target (round 4)
+    ('configs[3] at full size on one GPU: 1M x 30k, latent 64, k = 15 (one encode call of 1M rows, one 1M x 1M search per step)',
+     ['--cells', '1000000']),
+    ('configs[4] at full size on one GPU: 500k x 33k, fp16 operands, k = 50 (one 500k x 500k search per step)',
+     ['--cells', '500000', '--genes', '33000', '--k', '50', '--dtype', 'f16']),
 ]
 KNN_ROWS = [
     ("configs[3]: one rank's search, 125 000 queries x 1 000 000 candidates, d = 64, k = 15", ['1000000', '64', '15', '125000', '3']),
