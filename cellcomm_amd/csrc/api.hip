@@ -13,7 +13,6 @@ static thread_local std::string g_err;
 static hipStream_t g_stream = nullptr;    // the library stream
 static hipStream_t g_stream2 = nullptr;   // second stream: alternate passes of a short encode call run on it
 static hipStream_t g_cur = nullptr;       // stream the launchers currently issue on (g_stream unless overridden)
-static hipEvent_t g_lead_done = nullptr;  // orders the overlapped pass pair of a short encode call behind its full passes
 static hipEvent_t g_slot_free[2] = {nullptr, nullptr}, g_slot_full[2] = {nullptr, nullptr};   // cc_encode_dense pipeline
 static int g_device = -1;
 static int g_generation = 0;
@@ -535,35 +534,42 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
     }
     return CC_OK;
   }
-  // Pass plan.  GEMM time is quantised in rounds of 768 resident tiles, so a short pass leaves most
-  // CUs idle in its final round.  Calls of 2-4 passes (the per-rank shards at 4 and 8 GPUs) are cut
-  // into equal passes that alternate between two streams with their own workspaces: the idle CUs of
-  // one pass's last round then take tiles of the other.  Calls of 5-8 passes (2 GPUs) do the same
-  // with their last two passes only.  Longer calls (the 100k single-GPU case: 8192-row passes are
-  // exactly 2 + 1 rounds for layers 1 and 2) stay on one stream, where per-kernel timings also
-  // stay meaningful.
+  // Pass plan.  GEMM time is quantised in rounds of resident tiles (fp32: 3 per CU), and every pass ends in a partial
+  // round per layer.  fp32 (round 4): ONE stream; a call of at most two default passes runs as a single pass of all its
+  // rows — its whole rounds are as efficient as any, and only ONE partial round per layer is left, which launch_gemm
+  // runs as half-height tiles (five resident per CU: 0.94 of a round time for a full round of them, pro rata below
+  // that).  Measured against the two-stream plan of rounds 1-3 (passes cut in halves that alternate between the two
+  // library streams so that each fills the other's partial rounds; tools/experiments/README.md, gemm_tail_ab): configs[1]
+  // (10k x 20k) 920k -> 972k cells/s, a 12.5k-row shard step 27.5 -> 25.x ms, 25k / 50k rows 53.2 / 104.9 -> 53.0 /
+  // 104.0 ms; per-kernel timings mean one kernel again.  Longer calls keep the default pass (8192 rows at G = 30000:
+  // exactly 2 + 1 rounds for layers 1 and 2) and a short last pass.  The fp16 kernels (one workgroup per CU) keep the
+  // two-stream form for one short pass, below.
   struct Pass { int64_t off, m; int slot; };
   std::vector<Pass> plan;
-  int64_t lead_passes = 0;   // full passes in front of the overlapped pair (stream 2 waits for them)
   const int64_t full = e->batch;
   const int64_t npass = ceil_div(n, full);
   int64_t B = n < full ? n : full;
   bool dual = false;
-  // (fp32 kernels only: 3 workgroups per CU leave room for the other stream's tiles; the fp16 kernels take a CU's
-  // whole LDS per workgroup and gain nothing from a second stream — measured 36.4 -> 38.1 ms at C3)
-  // (a call that fits ONE pass of a width whose pass is larger than 8192 rows — 12288 at G = 20000 — but is longer
-  // than 8192 rows still runs as two halves: configs[1]'s 10k cells, 884k against 859k cells/s in one pass)
-  const int64_t np_dual = (npass == 1 && n > 8192) ? 2 : npass;
-  if (np_dual >= 2 && np_dual <= 8 && e->dtype == CC_DTYPE_F32) {
-    dual = true;
-    const int64_t lead = np_dual <= 4 ? 0 : np_dual - 2;          // full-size passes in front
-    lead_passes = lead;
-    int64_t off = 0;
-    for (int64_t i = 0; i < lead; ++i, off += full) plan.push_back({off, full, 0});
-    const int64_t rest = n - off, parts = np_dual - lead;
-    const int64_t each = round_up(ceil_div(rest, parts), GEMM_BM);
-    for (int64_t i = 0; off < n; ++i, off += each) plan.push_back({off, (n - off < each) ? n - off : each, (int)(i & 1)});
-    if (each > B || npass == 1) B = each;
+  if (e->dtype == CC_DTYPE_F32 && n <= 2 * full) {
+    // ... unless the single pass would end layer 1 in a nearly EMPTY partial round (a 12.5k-row shard at G = 30000:
+    // 3.06 rounds; a lone round of 48 tiles still costs ~0.6 of a round time, half-height or not): then the rows of the
+    // whole rounds form pass A and the few remaining rows pass B on the second stream, whose kernels fill the partial
+    // rounds of A's layer 2
+    const int64_t slots = 3 * (int64_t)num_cus(), nt1 = e->L[0].NT > 0 ? e->L[0].NT : 1;
+    const int64_t round_rows = slots % nt1 == 0 ? slots / nt1 * GEMM_BM : 0;
+    const int64_t A = round_rows > 0 ? n / round_rows * round_rows : 0, rest = n - A;
+#ifndef CC_F32_SPLIT_FRAC
+#define CC_F32_SPLIT_FRAC 0.35
+#endif
+    if (A > 0 && rest > 0 && (double)(ceil_div(rest, GEMM_BM) * nt1) < CC_F32_SPLIT_FRAC * (double)slots) {
+      dual = true;
+      B = A;
+      plan.push_back({0, A, 0});
+      plan.push_back({A, rest, 1});
+    } else {
+      B = n;
+      plan.push_back({0, n, 0});
+    }
   } else if (e->dtype != CC_DTYPE_F32 && npass == 1 && n >= 2 * GEMM16_TILE &&
              (double)ceil_div(n, GEMM16_TILE) * (double)e->L16[0].NT >= (double)num_cus() &&
              (double)ceil_div(n, GEMM16_TILE) * (double)e->L16[0].NT < 4.0 * (double)num_cus()) {
@@ -588,16 +594,9 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   if (dual) CC_HIP(hipStreamSynchronize(g_stream));   // workspace / h2_all memsets are on the library stream
   struct StreamReset { ~StreamReset() { g_cur = nullptr; g_two_streams = false; } } stream_reset;
   g_two_streams = dual;
-  if (lead_passes > 0 && !g_lead_done) CC_HIP(hipEventCreateWithFlags(&g_lead_done, hipEventDisableTiming));
-  int64_t pass_no = 0;
   for (const Pass &ps : plan) {
     const int sl = ps.slot;
     const int64_t off = ps.off, m = ps.m;
-    if (lead_passes > 0 && pass_no == lead_passes) {   // the overlapped pair starts together, after the full passes
-      CC_HIP(hipEventRecord(g_lead_done, g_stream));
-      CC_HIP(hipStreamWaitEvent(g_stream2, g_lead_done, 0));
-    }
-    ++pass_no;
     g_cur = sl ? g_stream2 : g_stream;
     const int64_t *d_ids = nullptr;
     if (row_ids) {
@@ -685,7 +684,7 @@ int cc_shutdown(void) {
   g_prof_on = false;
   for (hipEvent_t ev : g_event_pool) (void)hipEventDestroy(ev);
   g_event_pool.clear();
-  hipEvent_t *evs[] = {&g_lead_done, &g_slot_free[0], &g_slot_free[1], &g_slot_full[0], &g_slot_full[1]};
+  hipEvent_t *evs[] = {&g_slot_free[0], &g_slot_free[1], &g_slot_full[0], &g_slot_full[1]};
   for (hipEvent_t *ev : evs) {
     if (*ev) (void)hipEventDestroy(*ev);
     *ev = nullptr;

@@ -132,11 +132,7 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NAV
 // element's sum is the same sequence of v_mfma_f32_32x32x2_f32 steps either way, so results are bit-identical.
 template <int KCLASS, bool HALF>
 __global__
-#if CC_GEMM_MINWAVES > 0
-__launch_bounds__(GEMM_THREADS, CC_GEMM_MINWAVES)
-#else
-__launch_bounds__(GEMM_THREADS)
-#endif
+__launch_bounds__(GEMM_THREADS, HALF ? 5 : CC_GEMM_MINWAVES)
 void gemm_bias_act_kernel(const float *__restrict__ A1, int64_t lda1, const float *__restrict__ A2,
                           int64_t lda2, int64_t M, const f32x4 *__restrict__ Wp,
                           const float *__restrict__ bias, int KT1, int KT, int N, int MT, int NT,
@@ -336,14 +332,16 @@ int launch_gemm(const float *A1, int64_t lda1, const float *A2, int64_t lda2, in
   CC_REQUIRE(nwg < (int64_t)2147483647, "gemm: grid too large");
   ProfScope prof(prof_class, 2.0 * (double)M * (double)(W.K1 + W.K2) * (double)W.N);
   // Three workgroups per CU: the product runs in rounds of 3 x CUs tiles and its last round costs a whole tile time
-  // however few tiles it holds.  A last round that is at most half full runs as half-height tiles instead — two
-  // workgroups per tile, 64 rows each, on twice the slots — in a second launch behind the whole rounds (round 4, as
-  // the fp16 kernels since round 3).  C3's 8192-row passes are whole rounds (24 / 12 column tiles x 64 = 2 / 1 rounds)
-  // and never take it; configs[1] (1264 tiles = 1.65 rounds), a 12.5k-row shard (3.06 rounds) and every call of a
-  // few rows do.  A row's sums are the same MFMAs in the same order either way: results do not change.
+  // however few tiles it holds.  A partial last round runs as half-height tiles instead — two workgroups per tile, 64
+  // rows each, five resident per CU (90 registers, 25 KiB of LDS) — in a second launch behind the whole rounds (round 4,
+  // as the fp16 kernels since round 3).  C3's 8192-row passes are whole rounds (24 / 12 column tiles x 64 = 2 / 1
+  // rounds) and never take it; configs[1] (1264 + 632 tiles = 1.65 + 0.82 rounds), a 12.5k-row shard (3.06 + 1.53) and
+  // every call of a few rows do.  A row's sums are the same MFMAs in the same order either way: results do not change.
   const int64_t slots = (CC_GEMM_MINWAVES > 0 ? CC_GEMM_MINWAVES : 3) * (int64_t)num_cus();
   const int64_t tail = nwg % slots;
-  const int64_t whole = (tail > 0 && 2 * tail <= slots) ? nwg - tail : nwg;   // tiles of the full-height launch
+  // (a full round of half-height tiles — 5 x CUs x 2 of them — takes 0.94 of a full-height round: halves pay for any
+  // tail below ~0.89 of a round; 0.85 used)
+  const int64_t whole = (tail > 0 && 20 * tail <= 17 * slots) ? nwg - tail : nwg;   // tiles of the full-height launch
 #define CC_LAUNCH_GEMM(KC, HV, GRID, TILE0)                                                                          \
   hipLaunchKernelGGL((gemm_bias_act_kernel<KC, HV>), dim3((unsigned)(GRID)), dim3(GEMM_THREADS), 0, stream(), A1,    \
                      lda1, A2, lda2, M, reinterpret_cast<const f32x4 *>(W.d_w), W.d_bias, (int)W.KT1,              \

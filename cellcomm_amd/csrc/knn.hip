@@ -968,7 +968,7 @@ __device__ __forceinline__ void wavebufc_flush(WaveBufC &wb, const float *__rest
     const int64_t ql = q0 + wb.qr[i];
     if (ql < n_q) {
       const unsigned cand = wb.cand[i];
-      const float fine = fine_dist(x + (q_begin + ql) * d, x + (int64_t)cand * d, d, vec);
+      const float fine = fine_dist_batched(x + (q_begin + ql) * d, x + (int64_t)cand * d, d, vec);   // = fine_dist, bit for bit
       if (fine <= T[ql]) {
         const int pos = atomicAdd(cursor + ql, 1);
         if (pos < cap) buf[ql * cap + pos] = ((u64)f32_to_ordered(fine) << 32) | (u64)cand;
@@ -985,7 +985,7 @@ __device__ __forceinline__ void wavebufc_flush(WaveBufC &wb, const float *__rest
 
 // the passing pairs of one 32 x 32 tile (acc = coarse distance − threshold: sign bit set = pass) as a lane mask:
 // bit (15 − e) = pair (this lane's query, candidate entry e) passes; 0 for the whole wave when the tile is rejected
-__device__ __forceinline__ unsigned collect16c_mask(f32x16 &acc, int64_t b, int64_t NB, int64_t self_blk, unsigned self_bit,
+__device__ __forceinline__ unsigned collect16c_mask(f32x16 &acc, int b, int NB, int self_blk, unsigned self_bit,
                                                     unsigned tail_vm, int min_first) {
   if (__any(b == self_blk) || b == NB - 1) {
     // masked pairs (the query itself, padding rows of the last block) become +0; plain bit arithmetic on a per-lane
@@ -1017,12 +1017,12 @@ __device__ __forceinline__ unsigned collect16c_mask(f32x16 &acc, int64_t b, int6
 // + query group.  One pair per lane and round, wave-uniform trip count (the rounds cost a ballot, a popcount and a
 // branch each: sharing them between the tiles of two blocks is what this grouping is for).
 template <int QW>
-__device__ __forceinline__ void collect16c_park(unsigned long long m64, int64_t b0, WaveBufC &wb,
+__device__ __forceinline__ void collect16c_park(unsigned long long m64, int b0, WaveBufC &wb,
                                                 const float *__restrict__ x, int d, int vec, int64_t q_begin,
                                                 const float *__restrict__ T, u64 *__restrict__ buf,
                                                 int *__restrict__ cursor, int64_t q0, int64_t n_q, int cap, int lane) {
   const int r = lane & 31, h = lane >> 5;
-  const unsigned cbase = (unsigned)(b0 * 32) + 4 * h;
+  const unsigned cbase = (unsigned)b0 * 32u + 4 * h;
   while (true) {
     const unsigned long long lm = __ballot(m64 != 0);
     if (!lm) break;
@@ -1046,78 +1046,116 @@ __device__ __forceinline__ void collect16c_park(unsigned long long m64, int64_t 
 // LDS-DMA (global_load_lds: a unit = 64 lanes x 16 bytes is contiguous in the panel and in LDS) through a ring of
 // C16C_NSTAGE buffers, the DMA running NSTAGE - 1 stages ahead of the MFMAs with counted vmcnt waits (at N = 1M
 // a quarter of the panel reads miss the L2 and take > 1 us: one stage ahead left the workgroup waiting at every
-// barrier), one barrier per stage.  A stage's fragments are read at its start, and the QW MFMA chains of a block go
-// back to back into separate accumulators so that the sign tests of one group run under the MFMAs of the next.
+// barrier), one barrier per stage.
+//
+// Round 4 (the counters of round 3 showed 5.7 scalar + 5.5 vector instructions per MFMA: control, not arithmetic):
+//  * a stage is CONTIGUOUS in the panel (blocks b .. b + CB - 1 = NU unit rows of 1 KiB back to back), so the DMA source
+//    is one wave-uniform running pointer advanced once per stage + a constant per-lane offset, and the NU rows are dealt
+//    to the four waves without duplicates (round 3 computed a clamped 64-bit block address per request — ~15 scalar
+//    instructions each — and issued 12 requests for 10 rows); the panel carries C16C_PAD_BLOCKS blocks of padding so a
+//    stage that straddles the end of the range needs no clamp (blocks beyond the range are loaded and not used);
+//  * block indices are 32-bit (N < 2^31: at most 2^26 blocks);
+//  * a stage is SPECIAL when it holds a block with one of the wave's own queries (self pairs), the partly filled last
+//    block, or the end of the range: only then the per-tile masking code runs (collect16c_mask); every other stage takes
+//    a straight path — MFMAs of all its tiles, the sign bits of each tile folded into a lane mask (16 v_alignbit), one
+//    parking call per pair of blocks — with no per-tile compare, ballot or branch;
+//  * when hits are rare (min_first: N large against the list size) the straight path first ORs ALL accumulators of a
+//    block pair (v_or3 tree) and rejects the pair with ONE ballot; only a pair with a hit looks at its tiles;
+//  * the parked pairs are re-evaluated with 32 coordinates in flight (fine_dist_batched: the same sum, bit for bit)
+//    instead of one dependent round trip per 4 coordinates.
 constexpr int C16C_NSTAGE = 4;
+constexpr int C16C_PAD_BLOCKS = 4;   // >= the largest CB: padding blocks behind the panel (knn_pack16_kernel fills them as "no candidate")
 // The stage barrier of the ring as the bare instruction: __syncthreads() carries a fence that waits vmcnt(0) while
 // LDS-DMA writes are pending, which drained the ring at every stage (round 3: the counted vmcnt in front of it was
 // followed by the fence's vmcnt(0) in the assembly).  Each wave's own fragment reads of the stage are consumed by its
 // MFMAs before it gets here, its own DMA pieces of the next stage are covered by the counted wait in front.
 __device__ __forceinline__ void knn_stage_barrier() {
-#ifdef CC_KNN_FENCED_BARRIER
-  __syncthreads();
-#else
   asm volatile("" ::: "memory");   // the compiler moves no LDS access across the barrier
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-#endif
 }
 template <int ND>
 struct C16C {
   static constexpr int CB = ND == 1 ? 4 : ND == 2 ? 4 : ND == 4 ? 2 : 1;   // candidate blocks per stage
   static constexpr int HU = (ND + 1) * 64;                                  // hi + norm units (16 B) of a block
   static constexpr int STAGE_U = CB * HU;
-  static constexpr int NU = CB * (ND + 1);                                  // 64-lane unit rows per stage
-  static constexpr int DPS = (NU + 3) / 4;                                  // DMA instructions per wave and stage
+  static constexpr int NU = CB * (ND + 1);                                  // 64-lane unit rows (1 KiB) per stage
+  static constexpr int DPS = (NU + 3) / 4;                                  // most DMA instructions a wave issues per stage
+  static_assert(CB <= C16C_PAD_BLOCKS, "panel padding");
   static constexpr size_t lds_bytes() {
     return sizeof(h8) * C16C_NSTAGE * STAGE_U + (sizeof(unsigned) + sizeof(int)) * 4 * COL_WB;
   }
 };
 
+// lane mask of one tile without any test: bit (15 - e) = sign of accumulator e
+__device__ __forceinline__ unsigned collect16c_signs(const f32x16 &acc) {
+  unsigned hm = 0;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) hm = __builtin_amdgcn_alignbit(hm, __float_as_uint(acc[e]), 31);
+  return hm;
+}
+// OR of the 16 accumulators of a tile (sign bit set = some pair of this lane passes)
+__device__ __forceinline__ unsigned collect16c_or(const f32x16 &acc) {
+  unsigned o = __float_as_uint(acc[0]) | __float_as_uint(acc[1]) | __float_as_uint(acc[2]);
+  o |= __float_as_uint(acc[3]) | __float_as_uint(acc[4]);
+  o |= __float_as_uint(acc[5]) | __float_as_uint(acc[6]);
+  o |= __float_as_uint(acc[7]) | __float_as_uint(acc[8]);
+  o |= __float_as_uint(acc[9]) | __float_as_uint(acc[10]);
+  o |= __float_as_uint(acc[11]) | __float_as_uint(acc[12]);
+  o |= __float_as_uint(acc[13]) | __float_as_uint(acc[14]);
+  o |= __float_as_uint(acc[15]);
+  return o;
+}
+
 template <int ND, int QW>
 __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
-    const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin,
-    int64_t n_q, int include_self, const float *__restrict__ T, float s, int S, int64_t NBs, int cap,
+    const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d, int NB, int64_t q_begin,
+    int64_t n_q, int include_self, const float *__restrict__ T, float s, int S, int NBs, int cap,
     u64 *__restrict__ buf, int *__restrict__ cursor, int min_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using C_ = C16C<ND>;
   constexpr int NT = ND + 1;                 // units per candidate block in the panel
   constexpr int CB = C_::CB, HU = C_::HU, STAGE_U = C_::STAGE_U, NU = C_::NU, DPS = C_::DPS, NSTAGE = C16C_NSTAGE;
   constexpr int QPW = 32 * QW;               // queries per wave
+  constexpr int PB = CB >= 2 ? 2 : 1;        // blocks handled (and parked) together: PB * QW <= 4 tiles = the 64 mask bits of a lane
   h8 *stage = reinterpret_cast<h8 *>(smem);  // [NSTAGE][STAGE_U], then the 4 parking buffers
 
-  const int64_t tile = blockIdx.x / S;
-  const int split = blockIdx.x % S;
-  const int64_t b_lo = split * NBs;
-  const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
+  const int tile = (int)(blockIdx.x / (unsigned)S);
+  const int split = (int)(blockIdx.x % (unsigned)S);
+  const int b_lo = split * NBs;
+  const int b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, h = lane >> 5;
   const float s2 = s * s;
   const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
-  const int64_t q0 = tile * (4 * QPW) + wave * QPW;
-  const int64_t nstages = (b_hi - b_lo + CB - 1) / CB;
+  const int64_t q0 = (int64_t)tile * (4 * QPW) + wave * QPW;
+  const int nstages = (b_hi - b_lo + CB - 1) / CB;
 
-  // every wave issues DPS instructions per stage (the vmcnt arithmetic needs equal counts): unit rows beyond NU
-  // repeat the last one, blocks beyond the range repeat its last block
-  auto issue = [&](int64_t st, int slot) {
+  // DMA: unit rows u = wave, wave + 4, .. < NU of a stage; source = running wave-uniform pointer + lane * 16
+  const int my_dps = (NU - wave + 3) / 4;    // wave-uniform, DPS or DPS - 1
+  const char *gsrc = reinterpret_cast<const char *>(P16 + (int64_t)b_lo * (NT * 64)) + wave * 1024;
+  const unsigned voff = (unsigned)lane * 16u;
+  auto issue = [&](int slot) {
 #pragma unroll
-    for (int i = 0; i < DPS; ++i) {
-      int u = wave + 4 * i;
-      u = u < NU ? u : NU - 1;
-      const int cb = u / (ND + 1), t = u - cb * (ND + 1);
-      int64_t b = b_lo + st * CB + cb;
-      b = b < b_hi ? b : b_hi - 1;
-      CC_KNN_GLDS16(P16 + (b * NT + t) * 64 + lane, stage + (slot * STAGE_U + u * 64));
-    }
+    for (int i = 0; i < DPS; ++i)
+      if (wave + 4 * i < NU)   // wave-uniform
+        CC_KNN_GLDS16(gsrc + i * 4096 + voff, stage + (slot * STAGE_U + (wave + 4 * i) * 64));
+    gsrc += NU * 1024;
+  };
+  // wait until at most `keep` of this wave's stages are still in flight (a stage = my_dps instructions)
+  auto wait_stages = [&](bool counted) {
+    if (!counted) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (my_dps == DPS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * (DPS - 1)) : "memory");
   };
 #pragma unroll
   for (int p = 0; p < NSTAGE - 1; ++p)
-    if (p < nstages) issue(p, p);   // under the set-up below
+    if (p < nstages) issue(p);   // under the set-up below
 
   h8 bqh[QW][ND + 1];
-  int64_t self_blk[QW];
+  int self_blk[QW];
   unsigned self_bit[QW];
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
@@ -1141,11 +1179,15 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     if (qvalid && !include_self) {
       const int row = (int)(q & 31);
       if (((row >> 2) & 1) == h) {
-        self_blk[g] = q >> 5;
+        self_blk[g] = (int)(q >> 5);
         self_bit[g] = 1u << ((row & 3) | ((row >> 3) << 2));
       }
     }
   }
+  // the candidate blocks that hold one of this wave's own queries (wave-uniform; empty when self pairs are admitted)
+  const int sp_lo = include_self ? 0x7fffffff : (int)((q_begin + q0) >> 5);
+  const int sp_hi = include_self ? -1 : (int)((q_begin + q0 + QPW - 1) >> 5);
+  const int tail_blk = (N & 31) ? NB - 1 : 0x7fffffff;   // the partly filled last block, if any
   WaveBufC wb;
   wb.cand = reinterpret_cast<unsigned *>(smem + sizeof(h8) * NSTAGE * STAGE_U) + wave * COL_WB;
   wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * NSTAGE * STAGE_U + sizeof(unsigned) * 4 * COL_WB) + wave * COL_WB;
@@ -1154,53 +1196,92 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
   unsigned tail_vm = 0xffffu;
 #pragma unroll
   for (int e = 0; e < 16; ++e)
-    if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
+    if ((int64_t)(NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
 
   // stage 0 must have landed; NSTAGE - 2 later ones may stay in flight
-  if (nstages >= NSTAGE - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  wait_stages(nstages >= NSTAGE - 1);
   knn_stage_barrier();
 
   int slot = 0;
-  for (int64_t st = 0; st < nstages; ++st) {
+  for (int st = 0; st < nstages; ++st) {
     // the slot written now was read one stage ago, and every wave is past that barrier
     const bool ahead = st + NSTAGE - 1 < nstages;
-    if (ahead) issue(st + NSTAGE - 1, (slot + NSTAGE - 1) % NSTAGE);
+    if (ahead) issue(slot >= 1 ? slot - 1 : NSTAGE - 1);   // (slot + NSTAGE - 1) % NSTAGE
     const h8 *sbuf = stage + slot * STAGE_U + lane;
     h8 ah[CB][ND + 1];
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
       for (int t = 0; t <= ND; ++t) ah[cb][t] = sbuf[cb * HU + t * 64];
-    unsigned long long m64 = 0;
+    const int b0 = b_lo + st * CB;
+    // wave-uniform: no block of this stage needs a mask (own queries, padding rows) and all of them lie in the range
+    const bool plain = b0 + CB <= b_hi && (b0 > sp_hi || b0 + CB <= sp_lo) && b0 + CB <= tail_blk;
+    if (plain) {
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-      const int64_t b = b_lo + st * CB + cb;
-      if (b < b_hi) {   // workgroup-uniform
-        f32x16 acc[QW];
+      for (int pb = 0; pb < CB; pb += PB) {
+        f32x16 acc[PB][QW];
 #pragma unroll
-        for (int g = 0; g < QW; ++g) {
+        for (int c = 0; c < PB; ++c)
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+          for (int g = 0; g < QW; ++g) {
 #pragma unroll
-          for (int t = 0; t <= ND; ++t)
-            acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][t], bqh[g][t], acc[g], 0, 0, 0);
+            for (int e = 0; e < 16; ++e) acc[c][g][e] = 0.f;
+#pragma unroll
+            for (int t = 0; t <= ND; ++t)
+              acc[c][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb + c][t], bqh[g][t], acc[c][g], 0, 0, 0);
+          }
+        unsigned long long m64 = 0;
+        if (min_first) {
+          unsigned o[PB][QW], oall = 0;
+#pragma unroll
+          for (int c = 0; c < PB; ++c)
+#pragma unroll
+            for (int g = 0; g < QW; ++g) { o[c][g] = collect16c_or(acc[c][g]); oall |= o[c][g]; }
+          if (__any((int)oall < 0)) {
+#pragma unroll
+            for (int c = 0; c < PB; ++c)
+#pragma unroll
+              for (int g = 0; g < QW; ++g)
+                if (__any((int)o[c][g] < 0)) m64 |= (unsigned long long)collect16c_signs(acc[c][g]) << (16 * (c * QW + g));
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < PB; ++c)
+#pragma unroll
+            for (int g = 0; g < QW; ++g) m64 |= (unsigned long long)collect16c_signs(acc[c][g]) << (16 * (c * QW + g));
         }
-#pragma unroll
-        for (int g = 0; g < QW; ++g)
-          m64 |= (unsigned long long)collect16c_mask(acc[g], b, NB, self_blk[g], self_bit[g], tail_vm, min_first)
-                 << (16 * ((cb & 1) * QW + g));
+        collect16c_park<QW>(m64, b0 + pb, wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
       }
-      if ((cb & 1) || cb == CB - 1) {   // the tiles of two candidate blocks are parked together
-        collect16c_park<QW>(m64, b - (cb & 1), wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
-        m64 = 0;
+    } else {
+      unsigned long long m64 = 0;
+#pragma unroll
+      for (int cb = 0; cb < CB; ++cb) {
+        const int b = b0 + cb;
+        if (b < b_hi) {   // workgroup-uniform
+          f32x16 acc[QW];
+#pragma unroll
+          for (int g = 0; g < QW; ++g) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+#pragma unroll
+            for (int t = 0; t <= ND; ++t)
+              acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][t], bqh[g][t], acc[g], 0, 0, 0);
+          }
+#pragma unroll
+          for (int g = 0; g < QW; ++g)
+            m64 |= (unsigned long long)collect16c_mask(acc[g], b, NB, self_blk[g], self_bit[g], tail_vm, min_first)
+                   << (16 * ((PB == 2 ? (cb & 1) : 0) * QW + g));
+        }
+        if (PB == 1 || (cb & 1) || cb == CB - 1) {   // the tiles of PB candidate blocks are parked together
+          collect16c_park<QW>(m64, b - (PB == 2 ? (cb & 1) : 0), wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
+          m64 = 0;
+        }
       }
     }
     // the next stage's data must have landed (in the tail fewer stages are in flight than the count assumes)
-    if (ahead) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wait_stages(ahead);
     knn_stage_barrier();
-    slot = (slot + 1) % NSTAGE;
+    slot = slot == NSTAGE - 1 ? 0 : slot + 1;
   }
   wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
 }
@@ -1623,6 +1704,7 @@ struct KnnWorkspace {
   bool use_fp16_collect = true;            // stage 1b collect on the fp16 matrix cores when the data's scale allows
   bool use_fp64_prefilter = true;          // stage 3: float64 matrix-core prefilter in front of the exact scan
   bool use_coarse_collect = true;          // stage 1b collect on the fp16 tile + direct fp32 re-evaluation of the parked pairs; off: fp32 list collect
+  int collect_qw = 0;                      // 0 = chosen per call; 1 / 2 = 32-query groups per wave of the coarse collect
   int collect_splits = 0;                  // 0 = chosen per call; > 0 = forced (tools/knn_split_sweep.sh)
   int sample_splits = 0;                   // same for the candidate ranges of the fp16 sample pass
   int sample_stride = 0;                   // 0 = CC_KNN_SAMPLE; > 0 = every n-th candidate block is sampled
@@ -1630,7 +1712,18 @@ struct KnnWorkspace {
   int64_t last_fallback = 0;
   int64_t last_full_scan = 0;              // fallback queries that had to scan every candidate in float64 VALU
   int64_t last_sample_stride = 0;          // sampling stride of the last search that took route 1b with a sample (else 0)
+  // pinned bounce buffer for results that go to PAGEABLE caller memory (copy_results)
+  void *pin = nullptr;
+  size_t pin_cap = 0;
+  hipEvent_t pin_ev[4] = {nullptr, nullptr, nullptr, nullptr};
   void release() {
+    if (pin) (void)hipHostFree(pin);
+    pin = nullptr;
+    pin_cap = 0;
+    for (hipEvent_t &ev : pin_ev) {
+      if (ev) (void)hipEventDestroy(ev);
+      ev = nullptr;
+    }
     DevBuf *all[] = {&P, &P16, &norms, &maxn, &keys, &cnts, &bound, &skeys, &scnts, &smin, &Tq, &cbuf, &ccur, &oidx, &odist,
                      &nflag, &flagged, &bnd_d, &bnd_i, &partial, &mu, &norm64, &max64, &plist, &pcnt, &nfull, &full_list, &part_d,
                      &part_i};
@@ -1725,8 +1818,8 @@ static int run_collect16c(int ND, int QW, const h8 *P16, const SelectArgs &a, co
 #define CC_COL16C(NDV, QWV)                                                                                          \
   hipLaunchKernelGGL((knn_collect16c_kernel<NDV, QWV>), dim3((unsigned)nwg), dim3(256),                              \
                      C16C<NDV>::lds_bytes(), stream(),                                                                \
-                     P16, a.norms, maxnorm_bits, a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, \
-                     NBs, cap, buf, cursor, min_first)
+                     P16, a.norms, maxnorm_bits, a.x, a.mu, a.N, a.d, (int)a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, \
+                     (int)NBs, cap, buf, cursor, min_first)
   if (QW == 2) {
     switch (ND) {
       case 1: CC_COL16C(1, 2); break;
@@ -1755,6 +1848,54 @@ static void make_splits(int64_t NB, int want, int *S, int64_t *NBs) {
   while (s > 1 && (int64_t)(s - 1) * nbs >= NB) { --s; nbs = ceil_div(NB, s); }
   *S = s;
   *NBs = nbs;
+}
+
+// Results to the caller's host arrays.  Pinned destinations (the pipeline's buffers) take the DMA directly.  A PAGEABLE
+// destination made hipMemcpyAsync stage the copy itself at ~5 GB/s — 2-3 ms per 100k x 15 search outside any kernel
+// (knn_bench wall 5.6 ms against 3.6 ms of kernels).  Here such results cross the link into a pinned bounce
+// buffer of the workspace in four pieces, and the host copies piece i to the caller while pieces i+1.. are in flight.
+static bool host_ptr_is_pinned(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();   // unregistered host memory: clear the sticky error
+    return false;
+  }
+  return attr.type == hipMemoryTypeHost;
+}
+
+static int copy_results(KnnWorkspace &ws, const void *d_idx, const void *d_dist, size_t bytes_each, void *h_idx, void *h_dist) {
+  if (host_ptr_is_pinned(h_idx) && host_ptr_is_pinned(h_dist)) {
+    CC_HIP(hipMemcpyAsync(h_idx, d_idx, bytes_each, hipMemcpyDeviceToHost, stream()));
+    CC_HIP(hipMemcpyAsync(h_dist, d_dist, bytes_each, hipMemcpyDeviceToHost, stream()));
+    CC_HIP(hipStreamSynchronize(stream()));
+    return CC_OK;
+  }
+  if (ws.pin_cap < 2 * bytes_each) {
+    if (ws.pin) (void)hipHostFree(ws.pin);
+    ws.pin = nullptr;
+    ws.pin_cap = 0;
+    CC_HIP(hipHostMalloc(&ws.pin, 2 * bytes_each, hipHostMallocDefault));
+    ws.pin_cap = 2 * bytes_each;
+  }
+  for (hipEvent_t &ev : ws.pin_ev)
+    if (!ev) CC_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  char *pin_idx = static_cast<char *>(ws.pin), *pin_dist = pin_idx + bytes_each;
+  const size_t half = (bytes_each / 2 + 63) / 64 * 64 < bytes_each ? (bytes_each / 2 + 63) / 64 * 64 : bytes_each;
+  struct Piece { char *pin; const char *dev; char *dst; size_t off, len; };
+  const Piece pieces[4] = {{pin_idx, static_cast<const char *>(d_idx), static_cast<char *>(h_idx), 0, half},
+                           {pin_dist, static_cast<const char *>(d_dist), static_cast<char *>(h_dist), 0, half},
+                           {pin_idx, static_cast<const char *>(d_idx), static_cast<char *>(h_idx), half, bytes_each - half},
+                           {pin_dist, static_cast<const char *>(d_dist), static_cast<char *>(h_dist), half, bytes_each - half}};
+  for (int i = 0; i < 4; ++i) {
+    if (pieces[i].len) CC_HIP(hipMemcpyAsync(pieces[i].pin + pieces[i].off, pieces[i].dev + pieces[i].off, pieces[i].len,
+                                             hipMemcpyDeviceToHost, stream()));
+    CC_HIP(hipEventRecord(ws.pin_ev[i], stream()));
+  }
+  for (int i = 0; i < 4; ++i) {
+    CC_HIP(hipEventSynchronize(ws.pin_ev[i]));
+    if (pieces[i].len) memcpy(pieces[i].dst + pieces[i].off, pieces[i].pin + pieces[i].off, pieces[i].len);
+  }
+  return CC_OK;
 }
 
 int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_begin, int64_t n_q, int k,
@@ -1904,10 +2045,11 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
         }
       }
       if (scale16 > 0.f) {
-        const int64_t units = NB * (ND16 + 1) * 64;
+        // (+ C16C_PAD_BLOCKS blocks of "no candidate" behind the panel: the collect's stages are loaded whole)
+        const int64_t units = (NB + C16C_PAD_BLOCKS) * (ND16 + 1) * 64;
         if ((rc = P16.alloc(sizeof(h8) * (size_t)units))) return rc;
         hipLaunchKernelGGL(knn_pack16_kernel, dim3((unsigned)ceil_div(units, 256)), dim3(256), 0, stream(), d_x,
-                           mu.as<float>(), norms.as<float>(), N, d, ND16, NB, scale16, P16.as<h8>());
+                           mu.as<float>(), norms.as<float>(), N, d, ND16, NB + C16C_PAD_BLOCKS, scale16, P16.as<h8>());
       }
       // 1b-i: threshold from the sample (every SAMPLE-th candidate block)
       if (collect_all) {
@@ -1986,7 +2128,9 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
       // tools/knn_split_sweep.sh).  Each workgroup pays ~4 blocks' worth of set-up.
       const bool coarse = scale16 > 0.f && ws.use_coarse_collect && !collect_all;
       // 256 queries per workgroup once 8 ranges of them still fill a round
-      const int QW = (coarse && ND16 <= 4 && ceil_div(n_q, 256) * 8 >= 768) ? 2 : 1;
+      int QW = (coarse && ND16 <= 4 && ceil_div(n_q, 256) * 8 >= 768) ? 2 : 1;
+      if (coarse && ws.collect_qw == 1) QW = 1;
+      if (coarse && ws.collect_qw == 2 && ND16 <= 4) QW = 2;
       {
         int want = 8;
         const int forced = ws.collect_splits;
@@ -2145,10 +2289,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
     }
     ws.last_full_scan = h_full;
   }
-  CC_HIP(hipMemcpyAsync(h_idx, oidx.p, sizeof(int32_t) * (size_t)(n_q * k), hipMemcpyDeviceToHost, stream()));
-  CC_HIP(hipMemcpyAsync(h_dist, odist.p, sizeof(float) * (size_t)(n_q * k), hipMemcpyDeviceToHost, stream()));
-  CC_HIP(hipStreamSynchronize(stream()));
-  return CC_OK;
+  return copy_results(ws, oidx.p, odist.p, sizeof(float) * (size_t)(n_q * k), h_idx, h_dist);
 }
 
 }  // namespace cc
@@ -2188,6 +2329,10 @@ int cc_knn_set_option(void *knn, int option, int value) {
     case CC_KNN_OPT_SAMPLE_GROUPS:
       CC_REQUIRE(value >= 0 && value <= 2, "sample groups %d outside [0, 2]", value);
       ws->sample_qw = value;
+      break;
+    case CC_KNN_OPT_COLLECT_GROUPS:
+      CC_REQUIRE(value >= 0 && value <= 2, "collect groups %d outside [0, 2]", value);
+      ws->collect_qw = value;
       break;
     case CC_KNN_OPT_SAMPLE_STRIDE:
       CC_REQUIRE(value >= 0 && value <= 64, "sample stride %d outside [0, 64]", value);

@@ -85,6 +85,12 @@ def set_sample_layout(splits=0, stride=0, groups=0):
     _lib.check(_lib.lib().cc_knn_set_option(None, 9, int(groups)))
 
 
+def set_collect_groups(groups=0):
+    """Tuning / test hook: 32-query groups per wave of the coarse collect pass (1 or 2; 0 = chosen by the
+    library).  Results never depend on it (CC_KNN_OPT_COLLECT_GROUPS)."""
+    _lib.check(_lib.lib().cc_knn_set_option(None, 10, int(groups)))
+
+
 def use_fp64_prefilter(on):
     """Stage 3: narrow each uncertified query's candidates with a float64 matrix-core pass (default) before
     the exact evaluation, or scan all candidates; same results, different speed."""

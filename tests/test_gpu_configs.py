@@ -63,6 +63,12 @@ def test_config3_headline_size_properties(hip, oracle_built, c3):
     assert max_rel(out[rows], truth) <= 1e-4
     block = host.take(np.arange(36990, 42010))                                    # straddles pass boundaries of the full run
     assert np.array_equal(enc.predict(block), out[36990:42010])
+    # calls of at most two default passes take other plans (round 4): ONE pass of all rows whose partial last rounds run
+    # as half-height tiles (10 000 rows: 2.47 + 1.23 rounds), or — when layer 1 would end in a nearly empty round (a
+    # rank's 12 500 rows at 8 GPUs: 3.06) — the rows of the whole rounds on one stream and the remainder on the other.
+    # Same MFMAs in the same order per output element: the same bits as inside the 100k-row call.
+    for lo, hi in ((0, 12500), (87500, 100000), (40000, 50000), (3, 8195), (70000, 70064)):
+        assert np.array_equal(encode_range(enc, m, lo, hi), out[lo:hi]), (lo, hi)
     enc2 = cc.HipEncoder(e, g, 'cont', seed=4321, dtype='f16x2')
     out2 = enc2.predict(m)
     assert enc2.fp32_fallback_passes() == 0

@@ -172,6 +172,36 @@ def test_coarse_and_fp32_list_collect_agree(hip, oracle_built, kind):
         assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (kind, coarse)
 
 
+@pytest.mark.parametrize('n,d,k,dup', [(9000, 64, 15, True), (20011, 64, 50, False), (4100, 50, 15, True), (70000, 64, 15, False)])
+def test_collect_groups_never_change_the_result(hip, oracle_built, n, d, k, dup):
+    """The coarse collect runs 32 or 64 queries per wave (one or two query groups sharing every candidate fragment; a
+    four-group form at two waves per SIMD was built in round 4, measured 4-8 % slower and left as
+    tools/experiments/knn_collect_qw4.patch).  Whatever the form, and whatever the
+    number of candidate ranges (stages that straddle a range end, the padded end of the panel, the blocks that hold a
+    wave's own queries), the lists are the oracle's.  n = 70000 is checked on sampled queries."""
+    rng = np.random.default_rng(n + d + k)
+    x = rng.random((n, d), dtype=np.float32)
+    if dup:
+        x[rng.choice(n, n // 20, replace=False)] = x[rng.choice(n, n // 20)]
+    picks = np.arange(n) if n <= 21000 else np.concatenate([rng.choice(n, 60, replace=False), [0, 31, 32, n - 1]])
+    want = [ko.knn(x, k, q_begin=int(q), n_q=1) for q in picks] if n > 21000 else None
+    if want is None:
+        want_i, want_d = ko.knn(x, k)
+    try:
+        for groups, splits in [(1, 0), (2, 0), (2, 3), (2, 7), (1, 16), (1, 5)]:
+            hipknn.set_collect_groups(groups)
+            hip.cc_knn_set_option(None, 5, splits)
+            idx, dist = cc.knn_graph(x, k)
+            if want is None:
+                assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (groups, splits)
+            else:
+                for q, (wi, wd) in zip(picks, want):
+                    assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0]), (groups, splits, int(q))
+    finally:
+        hipknn.set_collect_groups(0)
+        hip.cc_knn_set_option(None, 5, 0)
+
+
 @pytest.mark.parametrize('n,d,k', [(600, 16, 15), (5000, 64, 15), (5000, 33, 50), (7000, 64, 128), (3000, 7, 100)])
 def test_sample_layouts_never_change_the_result(hip, oracle_built, n, d, k):
     """The threshold of stage 1b is the m-th smallest of the per-slot minima of the sampled tiles: 64 slots per query

@@ -21,7 +21,7 @@ print('mode', mode, flush=True)
 full = torch.sigmoid(torch.randn((N, E), device='cuda'))
 base = None
 rows = []
-for P in (1, 2, 4, 8):
+for P in (tuple(int(v) for v in os.environ['SHARD_P'].split(',')) if os.environ.get('SHARD_P') else (1, 2, 4, 8)):
     n = -(-N // P)
     m, _ = synth.synth_csr_device(n, G, seed=1234)
     pinned_enc = torch.empty((n, E), pin_memory=True)
