@@ -540,8 +540,9 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
   // runs as half-height tiles (five resident per CU: 0.94 of a round time for a full round of them, pro rata below
   // that).  Measured against the two-stream plan of rounds 1-3 (passes cut in halves that alternate between the two
   // library streams so that each fills the other's partial rounds; tools/experiments/README.md, gemm_tail_ab): configs[1]
-  // (10k x 20k) 920k -> 972k cells/s, a 12.5k-row shard step 27.5 -> 25.x ms, 25k / 50k rows 53.2 / 104.9 -> 53.0 /
-  // 104.0 ms; per-kernel timings mean one kernel again.  Longer calls keep the default pass (8192 rows at G = 30000:
+  // (10k x 20k) 890-920k -> 972k cells/s, 10k / 16k rows at G = 30000 22.5 / 34.4 -> 21.7 / 32.7 ms, 25k / 50k rows
+  // 53.2 / 104.9 -> 53.0 / 104.0 ms; a 12.5k- or 14k-row call stays within 2 % of the old plan (27.0 vs 26.5, 29.9 vs
+  // 29.7 ms: the two equal halves filled a 3.06-round product better); per-kernel timings mean one kernel again.  Longer calls keep the default pass (8192 rows at G = 30000:
   // exactly 2 + 1 rounds for layers 1 and 2) and a short last pass.  The fp16 kernels (one workgroup per CU) keep the
   // two-stream form for one short pass, below.
   struct Pass { int64_t off, m; int slot; };
@@ -558,10 +559,7 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
     const int64_t slots = 3 * (int64_t)num_cus(), nt1 = e->L[0].NT > 0 ? e->L[0].NT : 1;
     const int64_t round_rows = slots % nt1 == 0 ? slots / nt1 * GEMM_BM : 0;
     const int64_t A = round_rows > 0 ? n / round_rows * round_rows : 0, rest = n - A;
-#ifndef CC_F32_SPLIT_FRAC
-#define CC_F32_SPLIT_FRAC 0.35
-#endif
-    if (A > 0 && rest > 0 && (double)(ceil_div(rest, GEMM_BM) * nt1) < CC_F32_SPLIT_FRAC * (double)slots) {
+    if (A > 0 && rest > 0 && (double)(ceil_div(rest, GEMM_BM) * nt1) < 0.35 * (double)slots) {
       dual = true;
       B = A;
       plan.push_back({0, A, 0});
