@@ -33,7 +33,7 @@ PEAK_F16_MFMA_TFLOPS = 2500.0    # dense fp16/bf16 matrix
 PEAK_HBM_GBS = 8000.0
 PEAK_LDS_TBS = 157.3             # ds_read_b128: 256 B/clk/CU x 256 CUs x 2.4 GHz (the guide's LDS table; ~150 TB/s streaming)
 PCIE_GBS = 63.0                  # host link (spec), bounds the dense-host side numbers
-TRAFFIC_PROFILES = ('r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json')   # newest tracked PMC summary present   # tracked PMC summary that `roofline.traffic` is replayed from
+TRAFFIC_PROFILES = ('r04_pmc_hbm_traffic.json', 'r03_pmc_hbm_traffic.json', 'r02_pmc_hbm_traffic.json')   # newest tracked PMC summary present   # tracked PMC summary that `roofline.traffic` is replayed from
 
 
 def baseline_metric():
@@ -480,11 +480,12 @@ def main():
 
     if rank == 0:
         traffic = None   # HBM-side bytes per launch, REPLAYED from the PMC passes committed under profiles/
-        dominant = 'spmm_bias_act_kernel<1>' if args.sparse else 'gemm_bias_act_kernel<1>'
+        # (round 4: the layer-1 kernel of whole rounds is the instance <1, false>; <1, true> = its half-height tail tiles)
+        dominant = ('spmm_bias_act_kernel<1>',) if args.sparse else ('gemm_bias_act_kernel<1, false>', 'gemm_bias_act_kernel<1>')
         traffic_profile = next((f for f in TRAFFIC_PROFILES if os.path.exists(os.path.join(ROOT, 'profiles', f))), None)
         try:
             kernels = json.load(open(os.path.join(ROOT, 'profiles', traffic_profile)))['kernels']
-            pmc = next(v for k, v in kernels.items() if dominant in k)
+            pmc = next(v for name in dominant for k, v in kernels.items() if name in k)
             fetch = pmc['FETCH_SIZE']['mean_per_launch'] if isinstance(pmc['FETCH_SIZE'], dict) else pmc['FETCH_SIZE']
             write = pmc['WRITE_SIZE']['mean_per_launch'] if isinstance(pmc['WRITE_SIZE'], dict) else pmc['WRITE_SIZE']
             traffic = (2 * fetch + write) * 1024
@@ -515,7 +516,7 @@ def main():
                         'traffic': None if args.sparse else traffic,
                         'traffic_note': f'REPLAYED, not measured in this run: bytes per launch of the dominant kernel, '
                                         f'2*FETCH_SIZE+WRITE_SIZE from separate rocprofv3 --pmc passes of the same command '
-                                        f'(profiles/{traffic_profile}); algorithmic minimum 1.45e9 for the dense kernel',
+                                        f'(profiles/{traffic_profile}: one 8192-row launch, the shape of the timed passes); algorithmic minimum 1.45e9 for the dense kernel',
                         'avg_launch_ms': avg_ms, 'flop_per_launch': flop_per_launch}
         line = {
             'metric': baseline_metric(), 'value': args.cells * args.steps / elapsed,

@@ -69,7 +69,7 @@ class FreeMemoryWatch:
 def full_config(n, g, e, k, dtype, seed, seams, report_name):
     import torch
     torch.cuda.empty_cache()
-    free_start = torch.cuda.mem_get_info()[0]
+    free_start, total_mem = torch.cuda.mem_get_info()   # absolute figures below: whatever earlier tests of the session left cached is returned first
     t0 = time.perf_counter()
     m, keep = synth.synth_csr_device(n, g, seed=seed)
     t_synth = time.perf_counter() - t0
@@ -127,9 +127,10 @@ def full_config(n, g, e, k, dtype, seed, seams, report_name):
               'encode_cells_per_s': round(n / t_enc), 'knn_ms_one_call_incl_copy_out': round(t_knn * 1e3, 1),
               'knn_fallback_queries': fallback, 'knn_full_scan_queries': full_scan,
               'sampled_rows_max_rel_vs_oracle': rel, 'sampled_queries_bit_exact': len(picks),
-              'device_GiB_in_use_after_encode': round((free_start - free_after_encode) / 2**30, 2),
-              'device_GiB_in_use_after_knn': round((free_start - free_after_knn) / 2**30, 2),
-              'device_GiB_high_water_mark': round((free_start - watch.low) / 2**30, 2),
+              'device_GiB_used_after_encode': round((total_mem - free_after_encode) / 2**30, 2),
+              'device_GiB_used_after_knn': round((total_mem - free_after_knn) / 2**30, 2),
+              'device_GiB_used_high_water_mark': round((total_mem - watch.low) / 2**30, 2),
+              'device_GiB_used_before': round((total_mem - free_start) / 2**30, 2),
               'csr_GiB': round((nnz * 8 + (n + 1) * 8) / 2**30, 2)}
     os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
     with open(os.path.join(ROOT, 'gpurun_out', f'full_{report_name}.json'), 'w') as f:

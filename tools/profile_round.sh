@@ -21,12 +21,14 @@ cp $(find "$dst/stats" -name '*kernel_stats.csv' | head -1) "$dst/${tag}_bench_k
 rm -rf "$dst/stats"
 echo "stats done"; head -6 "$dst/${tag}_bench_kernel_stats.csv" | cut -c1-160
 K=gemm_bias_act,csr_gather,spmm_bias_act,gemm16_kernel,knn_
-python3 tools/pmc_run.py "$dst/${tag}_pmc_hbm_traffic.json" $K --groups tcc -- python3 $root/bench.py --cells 16384 --steps 2 --warmup 0 --no-cpu-baseline --no-dense-host 2>&1 | tail -n 12
+# (8192 cells = ONE pass of the default size: the launch shape of the timed 100k-cell run; since round 4 a call of up to two
+# default passes runs as one pass of all its rows, so 16384 cells would profile a launch twice as tall)
+python3 tools/pmc_run.py "$dst/${tag}_pmc_hbm_traffic.json" $K --groups tcc -- python3 $root/bench.py --cells 8192 --steps 2 --warmup 0 --no-cpu-baseline --no-dense-host --no-parity-check 2>&1 | tail -n 12
 (timeout -k 10 300 python3 $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt --dense-host 2>/dev/null | python3 -c "import json,sys; print(json.dumps(json.loads(sys.stdin.read().strip().splitlines()[-1])['dense_host'], indent=1))" > "$dst/${tag}_dense_host.json") || echo "dense-host run failed"
-python3 tools/pmc_run.py "$dst/${tag}_pmc_sq_dense.json" gemm_bias_act,csr_gather --groups sq -- python3 $root/bench.py --cells 8192 --steps 2 --warmup 0 --no-cpu-baseline --no-alt 2>&1 | tail -n 5
-python3 tools/pmc_run.py "$dst/${tag}_pmc_sq_sparse.json" spmm_bias_act,gemm_bias_act --groups sq -- python3 $root/bench.py --sparse --cells 16384 --steps 2 --warmup 0 --no-cpu-baseline --no-alt 2>&1 | tail -n 5
+python3 tools/pmc_run.py "$dst/${tag}_pmc_sq_dense.json" gemm_bias_act,csr_gather --groups sq -- python3 $root/bench.py --cells 8192 --steps 2 --warmup 0 --no-cpu-baseline --no-alt --no-parity-check 2>&1 | tail -n 5
+python3 tools/pmc_run.py "$dst/${tag}_pmc_sq_sparse.json" spmm_bias_act,gemm_bias_act --groups sq -- python3 $root/bench.py --sparse --cells 16384 --steps 2 --warmup 0 --no-cpu-baseline --no-alt --no-parity-check 2>&1 | tail -n 5
 for dt in f16 f16x2; do
-  python3 tools/pmc_run.py "$dst/${tag}_pmc_gemm16_$dt.json" gemm16_kernel --groups sq -- python3 $root/bench.py --dtype $dt --cells 32768 --steps 2 --warmup 0 --no-cpu-baseline --no-alt 2>&1 | tail -n 3
+  python3 tools/pmc_run.py "$dst/${tag}_pmc_gemm16_$dt.json" gemm16_kernel --groups sq -- python3 $root/bench.py --dtype $dt --cells 32768 --steps 2 --warmup 0 --no-cpu-baseline --no-alt --no-parity-check 2>&1 | tail -n 3
 done
 python3 tools/pmc_run.py "$dst/${tag}_pmc_knn_c3.json" knn_ --groups sq -- python3 $root/tools/knn_bench.py 100000 64 15 100000 2 2>&1 | tail -n 8
 python3 tools/pmc_run.py "$dst/${tag}_pmc_knn_c4rank.json" knn_ --groups sq -- python3 $root/tools/knn_bench.py 1000000 64 15 125000 1 2>&1 | tail -n 8
