@@ -113,3 +113,20 @@ def test_row_results_do_not_depend_on_batching(hip):
     assert np.array_equal(b.predict(m), out)
     perm = np.random.default_rng(2).permutation(n)
     assert np.array_equal(a.predict(m.take(perm)), out[perm])
+
+
+@pytest.mark.parametrize('n', [4097, 12288, 13001, 20000])
+def test_dense_host_rows_in_uneven_passes(hip, n):
+    """cc_encode_dense copies pass i + 1 under the kernels of pass i (two slots, 4096-row passes or the encoder's own
+    pass size when that is smaller).  Whatever the cut, a row's encoding is the encoding of the same row from the CSR
+    matrix, bit for bit."""
+    g, e = 1500, 16
+    m = synth.synth_csr(n, g, seed=n)
+    enc = cc.HipEncoder(e, g, 'cont', seed=9)
+    want = enc.predict(m)
+    dense = m.to_dense()
+    assert np.array_equal(enc.predict(dense), want)
+    few = cc.HipEncoder(e, g, 'cont', seed=9, batch_rows=1024)        # 1024-row passes, a ragged last one
+    assert np.array_equal(few.predict(dense), want)
+    rows = np.random.default_rng(n).choice(n, 40, replace=False)
+    assert max_rel(want[rows], eo.forward('cont', enc.get_weights(), dense[rows])) <= RTOL
