@@ -402,17 +402,12 @@ static int encoder_ensure_ws(Encoder *e, int64_t rows, int slots) {
     if ((rc = alloc_zero(&e->h4[sl], rows, e->ld3))) return rc;
     CC_HIP(hipMalloc(&e->d_row_ids[sl], sizeof(int64_t) * (size_t)rows));
     if (e->dtype != CC_DTYPE_F32) {
+      // fp16 pass buffers in the A16T layout (common.h): 256-row x 32-column tiles, so whole row blocks are allocated
+      // (the row-stride pad that kept rows of a row-major buffer off the same memory channels went with the rows)
       e->ldxh = round_up(e->G, 64);
-#ifndef CC_NO_STRIDE_PAD
-      // a row stride within 8 KiB of a NON-ZERO multiple of 64 KiB puts consecutive rows of an A tile on the same memory
-      // channels: layer 1 lost 2-5 % at configs[4]'s width (G = 33000: 64.5 KiB) and at C3's (G = 30000: 58.6 KiB, measured
-      // with and without, round 3).  One more 8 KiB of padding per row, which the gather neither writes nor the GEMM
-      // reads (the K loop stops at round_up(G, 64)).  Strides below 56 KiB (small gene sets) are left alone.
-      const int64_t stride_b = e->ldxh * 2, rem_b = stride_b % 65536;
-      if (stride_b >= 65536 - 8192 && (rem_b < 8192 || rem_b > 65536 - 8192)) e->ldxh += 4096;
-#endif
       e->ld1h = e->w0 == 0 ? 64 : round_up(e->w0, 64);
-      const size_t bx = sizeof(_Float16) * (size_t)(rows * e->ldxh), b1 = sizeof(_Float16) * (size_t)(rows * e->ld1h);
+      const int64_t rows256 = round_up(rows, 256);
+      const size_t bx = sizeof(_Float16) * (size_t)(rows256 * e->ldxh), b1 = sizeof(_Float16) * (size_t)(rows256 * e->ld1h);
       CC_HIP(hipMalloc(&e->xh[sl], bx));
       CC_HIP(hipMalloc(&e->h1h[sl], b1));
       CC_HIP(hipMalloc(&e->h1l[sl], b1));

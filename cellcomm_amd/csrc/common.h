@@ -139,9 +139,29 @@ struct PackedWeight16 {
   int TK = 32;
   int64_t K1 = 0, K2 = 0, KT1 = 0, KT2 = 0, N = 0, NT = 0;
 };
+// A16T — the layout of every fp16 activation matrix the fp16 GEMMs read (round 4): MFMA-operand tiles instead of rows.
+// A matrix of M rows x Kp columns (Kp a multiple of 32) is cut into tiles of 256 rows x 32 columns, stored tile after
+// tile, row block major: tile (mb, kb) = rows 256 mb .. 256 mb + 255, columns 32 kb .. 32 kb + 31 = 16 KiB contiguous;
+// inside a tile a row is 64 bytes = four 16-byte chunks, chunk c of row r at chunk position c ^ a16t_swz(r).  A tile is
+// byte for byte the LDS image the kernels read fragments from (rows as XOR-swizzled chunks: conflict-free
+// ds_read_b128 of the 16x16x32 fragments), so the LDS-DMA of a K-step is a straight copy of 16 / 32 contiguous KiB — one
+// KiB per wave instruction like the packed weights — where rows of a row-major matrix made every request touch
+// eight 128-byte pieces 60 KB apart (layer 1: 1438 -> 1550 TFLOP/s at C3's width, 1418 -> 1570 at configs[4]'s).
+// Buffers hold round_up(M, 256) rows; rows beyond M are never stored to a result.
+#if defined(__HIPCC__)
+#define CC_HD __host__ __device__
+#else
+#define CC_HD
+#endif
+CC_HD inline int a16t_swz(int row) { return (0x78 >> (2 * ((row >> 2) & 3))) & 3; }   // {0, 2, 3, 1}[(row >> 2) & 3]
+CC_HD inline int64_t a16t_offset(int64_t row, int64_t col, int64_t Kp) {               // in halfs
+  const int rl = (int)(row & 255);
+  return (((row >> 8) * (Kp >> 5) + (col >> 5)) * 256 + rl) * 32 + ((((int)(col >> 3) & 3) ^ a16t_swz(rl)) << 3) + (col & 7);
+}
+
 struct GemmSeg16 {
-  const void *A;   // fp16 [M x lda]
-  int64_t lda;     // in halfs, >= KT·TK (a multiple of 64 always suffices), zero beyond K
+  const void *A;   // fp16, A16T layout (above), M rows x lda columns
+  int64_t lda;     // columns Kp of the A16T matrix: a multiple of 32 (64 for one-plane weights), >= KT·TK, zero beyond K
   int which;       // 0: multiplies weight rows [0,K1), 1: rows [K1,K1+K2)
   int nterms;      // 1: W_hi, 2: W_hi + W_lo
 };

@@ -87,47 +87,63 @@ __device__ __forceinline__ void raise_fp16_flags(int bad, int *flags) {
   if ((any1 | any2) && (threadIdx.x & 63) == 0) atomicOr(flags, (any1 ? 1 : 0) | (any2 ? 2 : 0));
 }
 
-// fp16 output variant (CC_DTYPE_F16 / F16X2 encoders): same staging, the tile leaves as 8 halfs per
-// lane; *inexact gets bit 0 when a value does not survive the round trip through fp16 and bit 1 when a
-// finite value leaves the fp16 range (|v| > 65504 becomes inf: such a pass must run on the fp32 kernels
-// in BOTH fp16 modes — inf·0 in the MFMA would turn the row into NaN).
+// fp16 output variant (CC_DTYPE_F16 / F16X2 encoders): same staging; the rows leave in the A16T layout the fp16 GEMMs
+// copy straight into LDS (common.h: 256-row x 32-column tiles, rows as XOR-swizzled 16-byte chunks).  *inexact gets
+// bit 0 when a value does not survive the round trip through fp16 and bit 1 when a finite value leaves the fp16
+// range (|v| > 65504 becomes inf: such a pass must run on the fp32 kernels in BOTH fp16 modes — inf·0 in the MFMA
+// would turn the row into NaN).
 __global__ __launch_bounds__(GATHER_THREADS) void csr_gather_f16_kernel(
     const int64_t *__restrict__ indptr, const int32_t *__restrict__ indices,
     const float *__restrict__ vals, const int32_t *__restrict__ chunk_rel, int nc1,
-    const int64_t *__restrict__ row_ids, int64_t row_start, int nchunks, int64_t ld, int64_t wcols,
+    const int64_t *__restrict__ row_ids, int64_t row_start, int64_t n_rows, int nchunks, int64_t Kp,
     _Float16 *__restrict__ out, int *__restrict__ inexact) {
-  // TWO index chunks (8192 columns) per workgroup, staged as fp16: the same 16 KiB of LDS and of output per workgroup as
-  // the fp32 kernel (one chunk per workgroup wrote 8 KiB and ran at half its byte rate: 3.2 against 6.1 TB/s)
-  constexpr int CH = 2 * GATHER_CH;
-  __shared__ __attribute__((aligned(16))) _Float16 tile[CH];
+  // TWO consecutive output rows x one index chunk (4096 columns) per workgroup, staged as fp16: 16 KiB of LDS and of
+  // output per workgroup (a workgroup that writes 8 KiB runs at half the byte rate).  Rows r and r + 1 of an A16T tile
+  // are 64 bytes apart, so every 32-column block of the pair leaves as one 128-byte line.
+  constexpr int CH = GATHER_CH;
+  __shared__ __attribute__((aligned(16))) _Float16 tile[2][CH];
   const int tid = threadIdx.x;
-  const int64_t r = blockIdx.x / nchunks;
-  const int chunk = 2 * (int)(blockIdx.x % nchunks);
-  const int64_t row = row_ids ? row_ids[r] : row_start + r;
-  const int64_t c0 = (int64_t)chunk * GATHER_CH;
-  const int64_t c1 = (c0 + CH < wcols) ? c0 + CH : wcols;   // columns [G, wcols) are zero-filled; [wcols, ld) stay untouched
-  const int64_t beg = indptr[row];
-  const int32_t *rel = chunk_rel + row * nc1;
-  const int64_t lo = beg + rel[chunk < nc1 - 1 ? chunk : nc1 - 1];
-  const int64_t hi = beg + rel[chunk + 2 < nc1 - 1 ? chunk + 2 : nc1 - 1];
+  const int64_t r0 = 2 * (int64_t)(blockIdx.x / nchunks);
+  const int chunk = (int)(blockIdx.x % nchunks);
+  const int64_t c0 = (int64_t)chunk * CH;
 
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  float4 *tile4 = reinterpret_cast<float4 *>(tile);   // 8 halfs
+  float4 *tile4 = reinterpret_cast<float4 *>(&tile[0][0]);   // 8 halfs
 #pragma unroll
-  for (int i = tid; i < CH / 8; i += GATHER_THREADS) tile4[i] = z;
+  for (int i = tid; i < 2 * CH / 8; i += GATHER_THREADS) tile4[i] = z;
   __syncthreads();
   int bad = 0;
-  for (int64_t p = lo + tid; p < hi; p += GATHER_THREADS) {
-    const float v = vals[p];
-    bad |= fp16_flags(v);
-    tile[indices[p] - (int32_t)c0] = (_Float16)v;
+#pragma unroll
+  for (int rr = 0; rr < 2; ++rr) {
+    const int64_t r = r0 + rr;
+    if (r < n_rows) {   // workgroup-uniform
+      const int64_t row = row_ids ? row_ids[r] : row_start + r;
+      const int64_t beg = indptr[row];
+      const int32_t *rel = chunk_rel + row * nc1;
+      const int64_t lo = beg + rel[chunk < nc1 - 1 ? chunk : nc1 - 1];
+      const int64_t hi = beg + rel[chunk + 1 < nc1 - 1 ? chunk + 1 : nc1 - 1];
+      for (int64_t p = lo + tid; p < hi; p += GATHER_THREADS) {
+        const float v = vals[p];
+        bad |= fp16_flags(v);
+        tile[rr][indices[p] - (int32_t)c0] = (_Float16)v;
+      }
+    }
   }
   raise_fp16_flags(bad, inexact);
   __syncthreads();
 
-  float4 *orow = reinterpret_cast<float4 *>(out + r * ld + c0);
-  const int n8 = (int)((c1 - c0) >> 3);
-  for (int i = tid; i < n8; i += GATHER_THREADS) orow[i] = tile4[i];
+  // unit u = (32-column block j of the chunk, row rr, chunk position slot): 8 consecutive units = one 128-byte line
+  const int64_t kb32 = Kp >> 5;
+  for (int u = tid; u < CH / 32 * 8; u += GATHER_THREADS) {
+    const int j = u >> 3, rr = (u >> 2) & 1, slot = u & 3;
+    const int64_t kb = (c0 >> 5) + j, r = r0 + rr;
+    if (kb < kb32 && r < n_rows) {
+      const int rl = (int)(r & 255);
+      const int c = slot ^ a16t_swz(rl);   // the chunk that sits at this position
+      float4 *dst = reinterpret_cast<float4 *>(out + (((r >> 8) * kb32 + kb) * 256 + rl) * 32 + slot * 8);
+      *dst = *reinterpret_cast<const float4 *>(&tile[rr][j * 32 + c * 8]);
+    }
+  }
 }
 
 // ---- canonical-form check (replaces a serial host loop over every non-zero) -----------------------
@@ -205,46 +221,53 @@ int launch_gather(const int64_t *d_indptr, const int32_t *d_indices, const float
   return CC_OK;
 }
 
-// dense fp32 rows (cc_encode_dense) -> fp16 pass buffer, same exactness flag
+// dense fp32 rows (cc_encode_dense) -> fp16 pass buffer in the A16T layout, same exactness flags; one 16-byte chunk
+// (8 columns) per thread and step
 __global__ void convert_f32_f16_kernel(const float *__restrict__ x, int64_t ldx, int64_t M, int G,
-                                       _Float16 *__restrict__ out, int64_t ldo, int *__restrict__ inexact) {
-  const int64_t total = M * G;
+                                       _Float16 *__restrict__ out, int64_t Kp, int *__restrict__ inexact) {
+  using h8v = __attribute__((ext_vector_type(8))) _Float16;
+  const int64_t cpr = Kp >> 3, total = M * cpr;   // chunks per row
   int bad = 0;
   for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = t / G;
-    const int col = (int)(t % G);
-    const float v = x[row * ldx + col];
-    bad |= fp16_flags(v);
-    out[row * ldo + col] = (_Float16)v;
+    const int64_t row = t / cpr;
+    const int col = (int)(t % cpr) * 8;
+    h8v o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = col + j < G ? x[row * ldx + col + j] : 0.f;
+      bad |= fp16_flags(v);
+      o[j] = (_Float16)v;
+    }
+    *reinterpret_cast<h8v *>(out + a16t_offset(row, col, Kp)) = o;
   }
   raise_fp16_flags(bad, inexact);
 }
 
-int launch_convert_f16(const float *d_x, int64_t ldx, int64_t M, int G, void *d_out_half, int64_t ldo, int *d_inexact) {
+int launch_convert_f16(const float *d_x, int64_t ldx, int64_t M, int G, void *d_out_half, int64_t Kp, int *d_inexact) {
   if (M == 0) return CC_OK;
-  int64_t blocks = ceil_div(M * G, 256);
+  CC_REQUIRE(Kp % 32 == 0 && Kp >= G, "convert: %lld columns for G=%d (a multiple of 32 >= G)", (long long)Kp, G);
+  int64_t blocks = ceil_div(M * (Kp / 8), 256);
   if (blocks > 8192) blocks = 8192;
   hipLaunchKernelGGL(convert_f32_f16_kernel, dim3((unsigned)blocks), dim3(256), 0, stream(), d_x, ldx, M, G,
-                     static_cast<_Float16 *>(d_out_half), ldo, d_inexact);
+                     static_cast<_Float16 *>(d_out_half), Kp, d_inexact);
   CC_HIP(hipGetLastError());
   return CC_OK;
 }
 
 int launch_gather_f16(const int64_t *d_indptr, const int32_t *d_indices, const float *d_vals,
                       const int32_t *d_chunk_rel, const int64_t *d_row_ids, int64_t row_start, int64_t n, int G,
-                      int64_t ld, void *d_out_half, int *d_inexact, double nnz_hint) {
+                      int64_t Kp, void *d_out_half, int *d_inexact, double nnz_hint) {
   if (n == 0) return CC_OK;
-  CC_REQUIRE(ld % 8 == 0 && ld >= G, "gather: ld=%lld must be a multiple of 8 and >= G=%d", (long long)ld, G);
-  // the columns the GEMM reads: G rounded up to its K-step; a row stride beyond that (the 8 KiB pad that keeps fp16 row
-  // strides away from multiples of 64 KiB, api.hip) is neither written here nor read there
-  const int64_t wcols = round_up(G, 64) < ld ? round_up(G, 64) : ld;
-  const int nchunks = (int)ceil_div(wcols, 2 * GATHER_CH);   // two index chunks per workgroup
+  // Kp = the columns of the A16T matrix the rows are written into (G rounded up to the GEMM's K-step): columns
+  // [G, Kp) are written as zeros, the buffer holds round_up(n, 256) rows
+  CC_REQUIRE(Kp % 32 == 0 && Kp >= G, "gather: %lld columns for G=%d (a multiple of 32 >= G)", (long long)Kp, G);
+  const int nchunks = (int)ceil_div(Kp, GATHER_CH);   // one index chunk (and two rows) per workgroup
   const int nc1 = gather_chunk_count(G);
-  const int64_t nblocks = n * nchunks;
+  const int64_t nblocks = ceil_div(n, 2) * nchunks;
   CC_REQUIRE(nblocks < (int64_t)2147483647, "gather: grid too large (%lld blocks)", (long long)nblocks);
-  ProfScope prof(CC_PROF_GATHER, 8.0 * nnz_hint + 8.0 * (double)n + 2.0 * (double)wcols * (double)n);
+  ProfScope prof(CC_PROF_GATHER, 8.0 * nnz_hint + 8.0 * (double)n + 2.0 * (double)Kp * (double)n);
   hipLaunchKernelGGL(csr_gather_f16_kernel, dim3((unsigned)nblocks), dim3(GATHER_THREADS), 0, stream(), d_indptr,
-                     d_indices, d_vals, d_chunk_rel, nc1, d_row_ids, row_start, nchunks, ld, wcols,
+                     d_indices, d_vals, d_chunk_rel, nc1, d_row_ids, row_start, n, nchunks, Kp,
                      static_cast<_Float16 *>(d_out_half), d_inexact);
   CC_HIP(hipGetLastError());
   return CC_OK;

@@ -16,10 +16,14 @@
 //
 // Structure.  256 x 256 tile per 512-thread workgroup (one per CU), 8 waves as 2 x 4, 128 x 64 per wave = 8 x 4 blocks of
 // 16 x 16 (128 accumulator registers).  Operands reach LDS by LDS-DMA (global_load_lds, 16 bytes per lane, no staging
-// registers) with counted vmcnt and bare s_barrier; A rows sit in LDS as 16-byte chunks whose index is XOR-swizzled by
-// the row so that the fragment reads of the 16x16x32 shape are bank-conflict free (the DMA writes linearly, so the
-// swizzle is applied to the per-lane global source address); a weight plane is packed as the linear LDS image
-// [k / 8][256 columns][8 halfs].  With two planes the A fragments of a K-step are used against W_hi and W_lo.
+// registers) with counted vmcnt and bare s_barrier; A rows sit in LDS as 16-byte chunks whose position is XOR-swizzled by
+// the row so that the fragment reads of the 16x16x32 shape are bank-conflict free, in planes of 32 k ([k / 32][256
+// rows][4 chunks]); a weight plane is packed as the linear LDS image [k / 8][256 columns][8 halfs].  BOTH operands are
+// stored in HBM as their LDS images — the weights since round 2, the activations since round 4 (A16T, common.h: the
+// gather, the dense-host converter and layer 1's epilogue write 256-row x 32-column tiles with the swizzle applied) —
+// so every LDS-DMA instruction copies one contiguous KiB (round 3 swizzled the per-lane source address of row-major
+// rows instead: eight 128-byte pieces 60 KB apart per instruction, +8-9 % on the one-plane layers when they went).
+// With two planes the A fragments of a K-step are used against W_hi and W_lo.
 // THREE K-loop forms (all issue the same MFMAs in the same order per accumulator: results do not depend on which runs):
 //   gemm16_segment_pp    whole rounds of tiles, one plane: ping-pong of the two wave groups, K-step 64, 2 x 64 KiB
 //   gemm16_segment_pp2   whole rounds, two planes, two-term segments: the same over K-step 32, 3 x 48 KiB {A, W_hi, W_lo}
@@ -55,8 +59,8 @@ template <int PLANES> struct Cfg16 {
 };
 
 struct Seg16 {
-  const _Float16 *A;   // [M x lda] fp16
-  int64_t lda;         // halfs
+  const _Float16 *A;   // fp16, A16T layout (common.h): 256-row x 32-column tiles of 16 KiB
+  int64_t lda;         // columns of the A16T matrix (a multiple of 32)
   int KT;              // K-steps of this segment
   int wkt0;            // first K-step of the packed weight this segment multiplies
   int nterms;          // 1: W_hi only, 2: W_hi and W_lo
@@ -95,8 +99,8 @@ __device__ __forceinline__ void step_sync16() {
 // DMA sources of a K-segment: wave-uniform base pointers (SGPR pairs, advanced by scalar adds) plus per-lane byte
 // offsets that stay constant over the whole segment, so the K loop spends no vector instruction on addresses.
 template <int PLANES> struct Src16 {
-  const char *a_base[Cfg16<PLANES>::A_INSTR];   // row block i of the tile, K-step 0 of the segment
-  unsigned a_voff[Cfg16<PLANES>::A_INSTR];      // (row inside the block, swizzled chunk) of this lane
+  const char *a_base[Cfg16<PLANES>::A_INSTR];   // piece i (8 KiB) of the A16T tiles of the current K-step
+  unsigned a_voff[Cfg16<PLANES>::A_INSTR];      // tid * 16: the tiles are copied as they are
   const char *b_base;                           // packed weight tile of K-step 0
   unsigned b_voff;
 };
@@ -117,7 +121,7 @@ __device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], Src16<PLANES>
 #pragma unroll
     for (int i = 0; i < C_::A_INSTR; ++i) {
       CC_GLDS16(src.a_base[i] + src.a_voff[i], sa + (i * H_THREADS + wave * 64) * 16);
-      src.a_base[i] += TK * 2;
+      src.a_base[i] += STAGE_A;   // the A16T tiles of the next K-step follow
     }
 #pragma unroll
     for (int i = 0; i < NPL * C_::B_INSTR; ++i)
@@ -223,21 +227,21 @@ __device__ __forceinline__ void gemm16_segment(f32x4 (&acc)[8][4], Src16<PLANES>
 // pieces stay in flight) one phase before its first read:
 //   P1(t): request W k0 of t+1 | P2(t): A k1 of t+1, wait k1 of t | P3(t): W k1 of t+1 | P4(t): A k0 of t+2, wait k0 of t+1
 struct SrcPP {
-  const char *a_cur[2];   // row blocks 0-127 / 128-255 of the tile, K-step t of the segment (wave-uniform)
-  unsigned a_voff[2];     // (row inside the block, swizzled chunk of a k-half) of this lane, bytes
+  const char *a_cur[2];   // the two 8 KiB halves of the first A16T tile (k-half 0) of K-step t (wave-uniform)
+  unsigned a_voff[2];     // tid * 16
   const char *b_cur;      // packed weight tile of K-step t
   unsigned b_voff;
 };
 
 __device__ __forceinline__ void gemm16_segment_pp(f32x4 (&acc)[8][4], SrcPP src, int KT, char *smem, int a_lane, int b_lane,
                                                   int wave, int wm) {
-  constexpr int STAGE = 65536, A_PLANE = 16384, B_OFF = 32768, B_HALF = 16384, A_STEP = 128, B_STEP = 32768;
+  constexpr int STAGE = 65536, A_PLANE = 16384, B_OFF = 32768, B_HALF = 16384, A_STEP = 32768, B_STEP = 32768;
   // one DMA piece = 16 KiB = two instructions per thread
   auto issue_a = [&](int step, int kq, int stage) {   // A k-half kq of K-step t + step
     char *dst = smem + stage * STAGE + kq * A_PLANE;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
-      CC_GLDS16(src.a_cur[i] + (step * A_STEP + kq * 64) + src.a_voff[i], dst + (i * H_THREADS + wave * 64) * 16);
+      CC_GLDS16(src.a_cur[i] + (step * A_STEP + kq * A_PLANE) + src.a_voff[i], dst + (i * H_THREADS + wave * 64) * 16);
   };
   auto issue_b = [&](int step, int kq, int stage) {   // weight k-half kq of K-step t + step
     char *dst = smem + stage * STAGE + B_OFF + kq * B_HALF;
@@ -347,7 +351,7 @@ __device__ __forceinline__ void gemm16_segment_pp2(f32x4 (&acc)[8][4], Src16<2> 
   using C_ = Cfg16<2>;
   constexpr int NS = C_::NSTAGE, STAGE = C_::STAGE, STAGE_A = C_::STAGE_A, PLANE_B = C_::PLANE_B;
   static_assert(NS == 3 && C_::TK == 32 && C_::A_INSTR == 2 && C_::B_INSTR == 2, "ring of three 48 KiB stages");
-  constexpr int A_STEP = C_::TK * 2, B_STEP = 2 * PLANE_B;
+  constexpr int A_STEP = STAGE_A, B_STEP = 2 * PLANE_B;   // one A16T tile (16 KiB) per K-step of 32
   auto issue_a = [&](int x, int slot) {
     char *dst = smem + slot * STAGE;
 #pragma unroll
@@ -441,7 +445,7 @@ __device__ __forceinline__ void gemm16_segment_pp2(f32x4 (&acc)[8][4], Src16<2> 
 }
 
 // PLANES: weight planes in the packed matrix (1: CC_DTYPE_F16, 2: CC_DTYPE_F16X2).
-// OUT_MODE 0: C fp32 [M x ldc];  1: C_hi (and C_lo when split) fp16 planes [M x ldc]
+// OUT_MODE 0: C fp32 [M x ldc] row-major;  1: C_hi (and C_lo when split) fp16 planes, A16T layout of ldc columns
 template <int PLANES, int OUT_MODE, bool HALVES>
 __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64_t M, const _Float16 *__restrict__ Wp,
                                                               const float *__restrict__ bias, float inv_scale,
@@ -475,13 +479,12 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
   const int mode = m0 + wrow >= m_lim ? W_IDLE : (halves ? W_HALF : W_FULL);   // wave-uniform
   const int n0 = n_tile * H_TN;
 
-  // per-thread DMA geometry: LDS unit L = i * 512 + tid of the A image is (row L / CH, slot L % CH) and takes the
-  // global chunk slot ^ swz(row) of that row; rows beyond M re-read the last row (their results are not stored).
-  // Units i and i + 1 of a thread are 512 / CH rows apart and share the slot, so one offset serves all of them.
-  constexpr int ROWS_PER_INSTR = H_THREADS / CH;
-  const int a_row0 = tid / CH;
-  const int a_chunk = ((tid % CH) ^ swz16<CH>(a_row0)) << 3;     // swz16 depends on row mod 16 only; ROWS_PER_INSTR % 16 == 0
-  static_assert(ROWS_PER_INSTR % 16 == 0, "swizzle period");
+  // DMA geometry: the A operand is stored as A16T tiles (common.h) = the LDS image itself, so a K-step's A is STAGE_A
+  // contiguous bytes of the 256-row block this tile lies in, copied 8 KiB per instruction (thread tid: bytes tid * 16).
+  // A half-height workgroup copies the whole block's tiles and reads its own 128 rows of them.  Rows beyond M hold
+  // whatever the buffer holds; their results are not stored.
+  const int row_in_blk = halves ? (int)(blockIdx.x & 1) * (H_TM / 2) : 0;   // first row of this workgroup inside the 256-row block
+  (void)CH;
 
   f32x4 acc[8][4];
 #pragma unroll
@@ -493,9 +496,9 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
   int a_off[8][KQ];
 #pragma unroll
   for (int mt = 0; mt < 8; ++mt) {
-    const int row = wrow + mt * 16 + r16;   // (half-height tiles use row blocks 0-3 only)
+    const int row = row_in_blk + wrow + mt * 16 + r16;   // (half-height tiles use row blocks 0-3 only)
 #pragma unroll
-    for (int kq = 0; kq < KQ; ++kq) a_off[mt][kq] = (row * CH + ((4 * kq + q) ^ swz16<CH>(row))) * 16;
+    for (int kq = 0; kq < KQ; ++kq) a_off[mt][kq] = kq * 16384 + (row * 4 + (q ^ swz16<4>(row))) * 16;   // k-half plane kq of the stage
   }
   const int b_off = STAGE_A + (q * 256 + wn * 64 + r16) * 16;   // + plane * PLANE_B + kq * 16384 + nt * 256
 
@@ -504,16 +507,12 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
     const int KT = sg.KT;
     if (KT == 0) continue;
     Src16<PLANES> src;
+    // tile (m_tile, 0) of this segment's A16T matrix; K-step t = the STAGE_A bytes at + t * STAGE_A
+    const char *a_tiles = reinterpret_cast<const char *>(sg.A) + (int64_t)m_tile * (sg.lda >> 5) * 16384;
 #pragma unroll
     for (int i = 0; i < C_::A_INSTR; ++i) {
-      // rows beyond M re-read row M - 1 (their results are not stored): the clamp goes into the per-lane offset, which
-      // may then be negative relative to the block's (uniform) base row — unsigned wrap-around adds up correctly only
-      // in 64 bits, so the base row itself is clamped to stay at or below every lane's row
-      const int64_t blk = m0 + i * ROWS_PER_INSTR, gr = blk + a_row0;
-      const int64_t base_row = blk < m_lim ? blk : m_lim - 1;
-      const int64_t row = gr < m_lim ? gr : m_lim - 1;
-      src.a_base[i] = reinterpret_cast<const char *>(sg.A + base_row * sg.lda);
-      src.a_voff[i] = (unsigned)(((row - base_row) * sg.lda + a_chunk) * 2);
+      src.a_base[i] = a_tiles + i * (H_THREADS * 16);
+      src.a_voff[i] = (unsigned)tid * 16u;
     }
     src.b_base = reinterpret_cast<const char *>(Wp + ((int64_t)n_tile * KTW + sg.wkt0) * (PLANES * TK * H_TN));
     src.b_voff = (unsigned)tid * 16u;
@@ -521,15 +520,10 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
     if constexpr (PLANES == 1 && !HALVES) {
       static_assert(C_::TK == 64 && C_::LDS == 131072, "ping-pong: K-step 64, two 64 KiB stages");
       SrcPP sp;
-      const int prow = tid >> 2;                                   // row inside a 128-row block
-      const int pchunk = ((tid & 3) ^ swz16<4>(prow)) << 3;        // halfs inside a k-half
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        const int64_t blk = m0 + i * 128, gr = blk + prow;
-        const int64_t base_row = blk < m_lim ? blk : m_lim - 1;
-        const int64_t row = gr < m_lim ? gr : m_lim - 1;
-        sp.a_cur[i] = reinterpret_cast<const char *>(sg.A + base_row * sg.lda);
-        sp.a_voff[i] = (unsigned)(((row - base_row) * sg.lda + pchunk) * 2);
+        sp.a_cur[i] = a_tiles + i * (H_THREADS * 16);
+        sp.a_voff[i] = (unsigned)tid * 16u;
       }
       sp.b_cur = src.b_base;
       sp.b_voff = src.b_voff;
@@ -567,9 +561,10 @@ __global__ __launch_bounds__(H_THREADS, 1) void gemm16_kernel(Segs16 segs, int64
           if (OUT_MODE == 0) {
             static_cast<float *>(C)[row * ldc + col] = z;
           } else {
-            const _Float16 zh = (_Float16)z;
-            static_cast<_Float16 *>(C)[row * ldc + col] = zh;
-            if (C_lo) static_cast<_Float16 *>(C_lo)[row * ldc + col] = (_Float16)(z - (float)zh);
+            const _Float16 zh = (_Float16)z;   // fp16 planes feed the next fp16 GEMM: A16T layout, ldc = its column count
+            const int64_t at = a16t_offset(row, col, ldc);
+            static_cast<_Float16 *>(C)[at] = zh;
+            if (C_lo) static_cast<_Float16 *>(C_lo)[at] = (_Float16)(z - (float)zh);
           }
         }
       }
@@ -671,8 +666,9 @@ int launch_gemm16(const GemmSeg16 *segs, int nsegs, int64_t M, const PackedWeigh
     const int64_t KT = g.which == 0 ? W.KT1 : W.KT2;
     CC_REQUIRE(g.nterms == 1 || (g.nterms == 2 && W.planes == 2), "gemm16: segment %d asks for %d terms of a %d-plane weight",
                i, g.nterms, W.planes);
-    CC_REQUIRE(KT == 0 || (g.A && g.lda >= KT * W.TK && g.lda % 8 == 0), "gemm16: segment %d needs lda >= %lld (got %lld)",
-               i, (long long)(KT * W.TK), (long long)g.lda);
+    CC_REQUIRE(KT == 0 || (g.A && g.lda >= KT * W.TK && g.lda % W.TK == 0),
+               "gemm16: segment %d needs an A16T matrix of a multiple of %d columns, >= %lld (got %lld)", i, (int)W.TK,
+               (long long)(KT * W.TK), (long long)g.lda);
     sg.s[i].A = static_cast<const _Float16 *>(g.A);
     sg.s[i].lda = g.lda;
     sg.s[i].KT = (int)KT;
