@@ -125,6 +125,13 @@ __device__ __forceinline__ void gemm_k_loop(f32x16 (&acc)[2][2], f32x4 (&ra)[NAV
   }
 }
 
+// (Round 4 also gave the half-height tiles a K loop of their own with the global -> register prefetch TWO K-steps ahead
+// (two register sets, peeled so that hipcc's counted vmcnt left the younger set in flight; 122 registers, four resident
+// per CU instead of five), on the theory that a lone tile of a partial round exposes the memory round trip at every
+// K-step: no gain — a 1696-row pass, configs[1], a batch of 32 all within 2 % — and configs[1] lost 6 % to the lower
+// occupancy.  A lone half-height tile needs 1 us of MFMA time per K-step (32 x 64 cycles on its one wave per SIMD) and takes
+// 3: the rest is the two barriers, the LDS round trip and the fragment reads of a K-step with nobody to overlap them,
+// not the global loads.  Dropped.)
 // KCLASS only names the instantiation (so profilers tell layer 1 / layer 2 / tail apart).
 // HALF: half-height tiles.  Every 128 x 128 tile of the launch is worked by TWO workgroups, each on 64 of its rows
 // (4 waves as 2 x 2 of 32 x 64: one row of MFMA blocks per wave instead of two; the W tile and the K loop unchanged),
