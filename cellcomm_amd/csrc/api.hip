@@ -553,7 +553,8 @@ static int encode_csr_dev(Encoder *e, Csr *c, const int64_t *row_ids, int64_t ro
     // rounds of A's layer 2.  (Starting B only behind A's layer 1, by an event, measured the same 26.9 ms of encode for
     // 12.5k rows: beside layer 1 B's workgroups push A's exactly filled rounds into a fourth one, behind it B's own
     // layer 1 -> layer 2 chain — two latency-bound tile times — ends later than A's layer 2.  The 12288 rows of pass
-    // A alone take 25.0 ms.)
+    // A alone take 25.0 ms.  Nor did a high-priority second stream change it — 27.0 — while it unbalanced the equal halves
+    // of the sparse and fp16 short calls: 7.8 -> 8.9 and 4.1 -> 4.5 ms per 12.5k-row shard step.)
     const int64_t slots = 3 * (int64_t)num_cus(), nt1 = e->L[0].NT > 0 ? e->L[0].NT : 1;
     const int64_t round_rows = slots % nt1 == 0 ? slots / nt1 * GEMM_BM : 0;
     const int64_t A = round_rows > 0 ? n / round_rows * round_rows : 0, rest = n - A;
