@@ -185,7 +185,10 @@ void cc_mtx_free(void *mtx);
  * indices (int32).  Requires k <= n_total - (include_self ? 0 : 1); supported 1 <= k <= 128,
  * 1 <= d <= 132, n_total < 2^31.  cc_knn_l2 / cc_knn_l2_dev / cc_knn_l2_sharded use the library's
  * default workspace (grow-only scratch, released by cc_shutdown; options set on it with
- * cc_knn_set_option(NULL, ..) outlive a shutdown). */
+ * cc_knn_set_option(NULL, ..) outlive a shutdown).  host_idx / host_dist may be pageable or pinned (hipHostMalloc /
+ * hipHostRegister / torch pin_memory): pinned arrays take the DMA directly, pageable ones are filled through a pinned
+ * bounce buffer of the workspace (ABI v105).  The search needs about 5 KB of device scratch per query at k = 15
+ * (n_q = 1 000 000: 5 GB), 12 KB at k = 50. */
 int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_self,
               int32_t *host_idx, float *host_dist);
 int cc_knn_l2_dev(const float *dev_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q,
