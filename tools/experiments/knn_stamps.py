@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Probe (round 4): s_memtime stamps inside the collect's stage loop (a library built from csrc/knn.hip + the stamp
-edits of tools/experiments/README.md, swapped in by ab_lib.sh): per stage of waves 0 and 2 of two workgroups, the ticks
+"""Probe (round 4): s_memtime stamps inside the collect's stage loop (a library built from csrc/knn.hip +
+tools/experiments/knn_stamps.patch, swapped in by ab_lib.sh): per stage of waves 0 and 2 of two workgroups, the ticks
 between the stamps.   python3 tools/experiments/knn_stamps.py <n> <nq> <k>"""
 import ctypes, os, sys
 import numpy as np
