@@ -996,12 +996,7 @@ int cc_knn_l2_dev(const float *dev_x, int64_t n_total, int d, int64_t q_begin, i
 int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_self, int32_t *host_idx,
               float *host_dist) {
   CC_REQUIRE(initialised(), "cc_init has not been called");
-  CC_REQUIRE(n_total > 0 && d > 0, "knn: empty input");
-  CC_REQUIRE(host_x != nullptr, "host_x is NULL");
-  DevPtr x;
-  CC_HIP(x.alloc(sizeof(float) * (size_t)(n_total * d)));
-  CC_HIP(hipMemcpy(x.p, host_x, sizeof(float) * (size_t)(n_total * d), hipMemcpyHostToDevice));
-  return knn_run(nullptr, x.as<float>(), n_total, d, 0, n_total, k, include_self, host_idx, host_dist);
+  return knn_run_host(nullptr, host_x, n_total, d, k, include_self, host_idx, host_dist);
 }
 
 // ---- profiling ----------------------------------------------------------------------------

@@ -207,6 +207,8 @@ int launch_spmm(const SpmmStream &st, int64_t row_start, int64_t n, const SpmmWe
 struct KnnWorkspace;
 KnnWorkspace *knn_default_ws();
 void knn_default_ws_release();
+int knn_run_host(KnnWorkspace *ws, const float *h_x, int64_t n_total, int d, int k, int include_self, int32_t *h_idx,
+                 float *h_dist);
 int knn_run(KnnWorkspace *ws, const float *d_x, int64_t n_total, int d, int64_t q_begin, int64_t n_q, int k,
             int include_self, int32_t *h_idx, float *h_dist);
 

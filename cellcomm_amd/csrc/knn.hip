@@ -1696,7 +1696,7 @@ __global__ __launch_bounds__(64) void knn_prefilter64_kernel(
 // the last call.  cc_knn_create / cc_knn_free own one; the convenience entry points (cc_knn_l2, cc_knn_l2_dev,
 // cc_knn_l2_sharded) use the library's default workspace, which cc_shutdown releases.
 struct KnnWorkspace {
-  DevBuf P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, smin, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
+  DevBuf xin, P, P16, norms, maxn, keys, cnts, bound, skeys, scnts, smin, Tq, cbuf, ccur, oidx, odist, nflag, flagged,
       bnd_d, bnd_i, partial, mu, norm64, max64, plist, pcnt, nfull, full_list, part_d, part_i;
   bool force_fallback = false;             // test hook: every query through the float64 stage
   bool force_route_a = false;              // test hook: always take the full-select route
@@ -1724,7 +1724,7 @@ struct KnnWorkspace {
       if (ev) (void)hipEventDestroy(ev);
       ev = nullptr;
     }
-    DevBuf *all[] = {&P, &P16, &norms, &maxn, &keys, &cnts, &bound, &skeys, &scnts, &smin, &Tq, &cbuf, &ccur, &oidx, &odist,
+    DevBuf *all[] = {&xin, &P, &P16, &norms, &maxn, &keys, &cnts, &bound, &skeys, &scnts, &smin, &Tq, &cbuf, &ccur, &oidx, &odist,
                      &nflag, &flagged, &bnd_d, &bnd_i, &partial, &mu, &norm64, &max64, &plist, &pcnt, &nfull, &full_list, &part_d,
                      &part_i};
     for (DevBuf *b : all) b->release();
@@ -2292,6 +2292,19 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
     ws.last_full_scan = h_full;
   }
   return copy_results(ws, oidx.p, odist.p, sizeof(float) * (size_t)(n_q * k), h_idx, h_dist);
+}
+
+// The same for points in HOST memory (cc_knn_l2): they cross the link into a grow-only buffer of the workspace (a
+// device allocation per call was ~0.3 ms of a 100k-point search).
+int knn_run_host(KnnWorkspace *wsp, const float *h_x, int64_t N, int d, int k, int include_self, int32_t *h_idx,
+                 float *h_dist) {
+  KnnWorkspace &ws = wsp ? *wsp : *knn_default_ws();
+  CC_REQUIRE(N > 0 && d > 0, "knn: empty input");
+  CC_REQUIRE(h_x != nullptr, "host_x is NULL");
+  int rc;
+  if ((rc = ws.xin.alloc(sizeof(float) * (size_t)(N * d)))) return rc;
+  CC_HIP(hipMemcpyAsync(ws.xin.p, h_x, sizeof(float) * (size_t)(N * d), hipMemcpyHostToDevice, stream()));
+  return knn_run(&ws, ws.xin.as<float>(), N, d, 0, N, k, include_self, h_idx, h_dist);
 }
 
 }  // namespace cc
