@@ -417,18 +417,22 @@ def main():
         alt_sparse = {'dtype': 'f32', 'value': args.cells * args.steps / sp_elapsed, 'unit': 'cells/s',
                       'ms_per_step': sp_elapsed / args.steps * 1e3,
                       'roofline': {'kernel': 'spmm_bias_act_kernel<1> (layer 1 over the non-zeros, fp32 vector FMAs)',
-                                   'bound': 'lds', 'achieved': lds_tbs, 'peak': PEAK_LDS_TBS, 'unit': 'TB/s',
-                                   'frac': lds_tbs / PEAK_LDS_TBS, 'traffic': None,
+                                   'bound': 'valu', 'achieved': nz_tflops, 'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': nz_tflops / PEAK_F32_MFMA_TFLOPS, 'traffic': None,
                                    'avg_launch_ms': s1['ms'] / max(s1['launches'], 1),
-                                   'lds_bytes_per_launch': s1['work'] / 2.0 * 4.0 / max(s1['launches'], 1),
                                    'flop_per_launch': s1['work'] / max(s1['launches'], 1),
-                                   'fp32_fma_tflops': nz_tflops, 'fp32_vector_peak_tflops': PEAK_F32_MFMA_TFLOPS,
-                                   'frac_of_vector_peak': nz_tflops / PEAK_F32_MFMA_TFLOPS,
+                                   'fp32_fma_tflops': nz_tflops,
+                                   'lds_bytes_per_launch': s1['work'] / 2.0 * 4.0 / max(s1['launches'], 1),
+                                   'lds_read_tbs': lds_tbs, 'lds_read_peak_tbs': PEAK_LDS_TBS,
+                                   'frac_of_lds_read_peak': lds_tbs / PEAK_LDS_TBS,
                                    'dense_equivalent_tflops': (2.0 * (hi - lo) * args.genes * enc.layers[1].units * args.steps
                                                                / (s1['ms'] * 1e-3) / 1e12) if s1['ms'] > 0 else None,
-                                   'note': 'achieved = algorithmic LDS read bytes (1 KiB per non-zero and 256-column panel '
-                                           '= 4 B per FMA) / kernel time; peak = 256 B/clk/CU x 256 CUs x 2.4 GHz. A kernel '
-                                           'of this shape (one weight read per FMA) cannot exceed half the vector peak.'},
+                                   'note': 'achieved = FMA FLOP over the non-zeros / kernel time against the fp32 vector peak '
+                                           '(= the fp32 MFMA figure on this part).  Round 4 probes (tools/experiments/README.md): '
+                                           'dropping half of the LDS weight reads changes nothing, dropping one of the five '
+                                           'vector instructions per entry 3-12 %: vector issue binds, not LDS bandwidth (the '
+                                           'LDS figures stay as secondary fields); 2 packed FMAs among 5 vector instructions '
+                                           'per entry cap a kernel of this shape at ~0.4 of the peak.'},
                       'stages_rank0': {k: {'launches': v['launches'], 'ms_per_step': v['ms'] / args.steps}
                                        for k, v in sp_prof.items() if v['launches']},
                       'note': 'sparse-aware first layer (SURVEY 8 f4): x @ K1 and the raw-input rows of K2 as CSR x dense '
