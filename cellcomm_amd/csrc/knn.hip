@@ -733,33 +733,90 @@ __device__ __forceinline__ float fine_dist_batched(const float *__restrict__ xq,
 // distinct candidates lie at or below T whatever the coarse values were worth.  T is a little looser than the m-th
 // best of the whole sample (two of the best m may share a slot: the expected rank is G·ln(G/(G-m)), 18.4 instead of
 // 16 at G = 64) but the pass costs 5 MFMAs + 32 vector instructions per tile where round 1's list select cost
-// 13 + 511, needs no LDS, and is cheap enough to sample every 4th block instead of every 8th.
+// 13 + 511, and is cheap enough to sample every 4th block instead of every 8th.
 constexpr int SKEY_BITS = 13;                       // sampled tiles per candidate range <= 8192
 constexpr unsigned SKEY_MASK = (1u << SKEY_BITS) - 1u;
 
+#define CC_KNN_GLDS16(src, dst)                                                             \
+  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src),   \
+                                   (void __attribute__((address_space(3))) *)(dst), 16, 0, 0)
+
+constexpr int SMP_WAVES = 4;   // waves of a sample workgroup = candidate tiles per round of its LDS ring
+
+// One sampled tile for one wave: ND + 1 fragment reads from the stage, (ND + 1)·QW MFMAs, then v_and_or_b32 +
+// v_min_u32 per distance.  MASKED = the tile may hold a query of this wave itself or the padding behind candidate N - 1.
+template <int ND, int QW, bool MASKED>
+__device__ __forceinline__ void sample16_tile(const h8 *__restrict__ frag, const h8 (&bqh)[QW][ND + 1],
+                                              __attribute__((ext_vector_type(16))) unsigned (&mn)[QW], unsigned keep,
+                                              unsigned j, int b, int NB, const int (&self_blk)[QW],
+                                              const unsigned (&self_bit)[QW], unsigned tail_vm) {
+  h8 ah[ND + 1];
+#pragma unroll
+  for (int t = 0; t <= ND; ++t) ah[t] = frag[t * 64];
+  f32x16 acc[QW];
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+#pragma unroll
+    for (int t = 0; t <= ND; ++t) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bqh[g][t], acc[g], 0, 0, 0);
+  }
+  unsigned jv;   // the tile index in a VECTOR register: see `keep`
+  asm volatile("v_mov_b32 %0, %1" : "=v"(jv) : "s"(j));
+#pragma unroll
+  for (int g = 0; g < QW; ++g) {
+    if (MASKED) {
+      if (__any(b == self_blk[g]) || b == NB - 1) {
+        const unsigned km = (b == self_blk[g] ? self_bit[g] : 0u) | (b == NB - 1 ? ~tail_vm & 0xffffu : 0u);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[g][e] = ((km >> e) & 1u) ? INFINITY : acc[g][e];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const unsigned key = (__float_as_uint(acc[g][e]) & keep) | jv;
+      mn[g][e] = key < mn[g][e] ? key : mn[g][e];
+    }
+  }
+}
+
+// Round 4: a workgroup of four waves (4·QW·32 queries) shares every sampled tile through LDS.  As one-wave workgroups
+// (rounds 2-3) each wave fetched its own copy of every tile, (ND + 1) KiB per (ND + 1)·QW MFMAs: 76 GB of L2 -> register
+// traffic at 125k x 1M, and hipcc spent 4 vector instructions per distance where 2 were meant (see `keep`).  Now wave w
+// brings tile 4r + w of round r into the stage of the round (LDS-DMA, issued one round ahead), and every wave works the
+// four tiles from there: a quarter of the fetches, one barrier per four tiles.  Keys, slots and therefore T[q] are the
+// same bits as before.  125k x 1M: 3.37 -> 2.45 ms, C3: 0.75 -> 0.55 ms, 62.5k x 500k (k = 50, QW = 1): 1.04 -> 0.90 ms.
+// Measured and NOT kept (tools/experiments/README.md): the MFMAs of a tile laid over the vector instructions of the
+// previous one by hand (sched_group_barrier: 7 % slower — an MFMA of this shape keeps the issue port for ~18 of its
+// 32 cycles, tools/experiments/mfma_valu_overlap.hip, and the other wave of the SIMD already fills the rest), a higher
+// priority for the wave in the odd slot of each SIMD (nothing).
 template <int ND, int NSET, int QW>
-__global__ __launch_bounds__(64) void knn_sample16_kernel(
+__global__ __launch_bounds__(64 * SMP_WAVES, 2) void knn_sample16_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
     const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d, int64_t NB, int64_t q_begin,
     int64_t n_q, int include_self, float s, int S, int64_t NBs, int bstride, unsigned *__restrict__ out_key) {
   constexpr int NT = ND + 1;
-  const int64_t tile = blockIdx.x / S;
+  static_assert(SMP_WAVES % NSET == 0, "tile t of a round feeds set t % NSET");
+  __shared__ h8 stage[2][SMP_WAVES][NT * 64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int64_t tile = (int64_t)(blockIdx.x / S) * SMP_WAVES + wave;   // this wave's QW groups of 32 queries
   const int split = blockIdx.x % S;
   const int64_t b_lo = split * NBs;
   const int64_t b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
-  const int lane = threadIdx.x;
   const int r = lane & 31, h = lane >> 5;
   const float s2 = s * s;
 
-  // QW query groups of 32 share every candidate fragment (half the fragment traffic per MFMA when QW = 2)
+  // QW query groups of 32 share every candidate fragment
   h8 bqh[QW][ND + 1];
-  int64_t self_blk[QW];
+  int self_blk[QW];        // block indices fit 32 bits: N < 2^31 (knn_run)
   unsigned self_bit[QW];
+  int first_blk[QW];   // wave-uniform: the blocks that can hold a query of group g are first_blk[g] and the next
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
     const int64_t ql = (tile * QW + g) * 32 + r;
     const bool qvalid = ql < n_q;
     const int64_t q = q_begin + ql;
+    first_blk[g] = (int)((q_begin + (tile * QW + g) * 32) >> 5);
 #pragma unroll
     for (int t = 0; t < ND; ++t)
       bqh[g][t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
@@ -773,10 +830,10 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
     }
     self_blk[g] = -1;
     self_bit[g] = 0;
-    if (!include_self) {   // (rows of invalid queries are masked like a self pair: their keys are never read)
+    if (!include_self) {   // (rows of invalid queries are never read back: nothing to mask)
       const int row = (int)(q & 31);
       if (qvalid && ((row >> 2) & 1) == h) {
-        self_blk[g] = q >> 5;
+        self_blk[g] = (int)(q >> 5);
         self_bit[g] = 1u << ((row & 3) | ((row >> 3) << 2));
       }
     }
@@ -787,59 +844,64 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
     if ((NB - 1) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h >= N) tail_vm &= ~(1u << e);
 
   using u32x16 = __attribute__((ext_vector_type(16))) unsigned;
-  u32x16 mn[QW][NSET];
+  u32x16 mn[NSET][QW];
 #pragma unroll
-  for (int g = 0; g < QW; ++g)
+  for (int u = 0; u < NSET; ++u)
 #pragma unroll
-    for (int u = 0; u < NSET; ++u)
+    for (int g = 0; g < QW; ++g)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) mn[g][u][e] = 0xffffffffu;
-  const unsigned keep = ~SKEY_MASK;   // in a register: v_and_or takes one scalar operand, the tile index
+      for (int e = 0; e < 16; ++e) mn[u][g][e] = 0xffffffffu;
+  // One v_and_or_b32 per distance needs the mask in a SCALAR register and the tile index in a VECTOR one (a gfx9 VOP3
+  // takes one scalar source and no literal).  Left to itself hipcc folded the mask into v_and_b32 + v_or_b32 with a
+  // literal, and with one wave per SIMD allowed it kept the tiles in AGPRs behind 16 v_accvgpr_read each: 4 vector
+  // instructions per distance where 2 were meant (now 1.5: hipcc fuses the updates of two tiles of a set into
+  // v_min3_u32); the launch bound asks for two waves per SIMD, i.e. MFMAs that write VGPRs.
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, 0xffffe000" : "=s"(keep));
+  static_assert(SKEY_BITS == 13, "the literal above is ~SKEY_MASK");
 
-  // two register sets of candidate operands, ping-pong: the next sampled block loads while this one computes
-  h8 ah[2][ND + 1];
-  {
-    const h8 *pb = P16 + b_lo * (NT * 64) + lane;
+  // sampled tiles of this range: i = 0 .. nt-1 at block b_lo + i·bstride; tile i feeds set i % NSET and carries i in its keys
+  const int64_t nt = b_hi > b_lo ? (b_hi - b_lo + bstride - 1) / bstride : 0;
+  const int64_t rounds = (nt + SMP_WAVES - 1) / SMP_WAVES;
+  // wave w brings tile 4·round + w into its quarter of the stage by LDS-DMA (no registers; a unit of 64 lanes x 16 bytes
+  // is contiguous in the panel and in LDS)
+  auto fetch = [&](int64_t round, int buf) {
+    int64_t i = round * SMP_WAVES + wave;
+    if (i >= nt) i = nt - 1;   // past the end: any valid tile, never worked
+    const h8 *pb = P16 + (b_lo + i * bstride) * (NT * 64) + lane;
 #pragma unroll
-    for (int t = 0; t <= ND; ++t) ah[0][t] = pb[t * 64];
-  }
-  unsigned j = 0;   // index of the sampled tile inside this range
-  for (int64_t b0 = b_lo; b0 < b_hi; b0 += (int64_t)NSET * bstride) {
+    for (int t = 0; t < NT; ++t) CC_KNN_GLDS16(pb + t * 64, &stage[buf][wave][t * 64]);
+  };
+  if (rounds > 0) fetch(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int64_t rd = 0; rd < rounds; ++rd) {
+    const int buf = (int)(rd & 1);
+    // the other half of the stage was read in round rd - 1 and every wave is past the barrier that ended it; the
+    // requests have this whole round to land
+    if (rd + 1 < rounds) fetch(rd + 1, buf ^ 1);
+    const int64_t i0 = rd * SMP_WAVES;
+    const int bf = (int)(b_lo + i0 * bstride), bl = bf + (SMP_WAVES - 1) * bstride;   // blocks of the round: bf .. bl
+    bool special = bl >= (int)NB - 1 || i0 + SMP_WAVES > nt;
 #pragma unroll
-    for (int u = 0; u < NSET; ++u) {
-      const int64_t b = b0 + (int64_t)u * bstride;
-      if (b < b_hi) {   // wave-uniform
-        const int cur = u & 1, nxt = cur ^ 1;   // constants after unrolling
-        {
-          const int64_t bn = b + bstride;
-          const h8 *pb = P16 + ((bn < b_hi) ? bn : b) * (NT * 64) + lane;
+    for (int g = 0; g < QW; ++g) special = special || (first_blk[g] + 1 >= bf && first_blk[g] <= bl);
+    if (!special) {   // wave-uniform: four whole tiles, none with a self pair or the padding: no branch inside
 #pragma unroll
-          for (int t = 0; t <= ND; ++t) ah[nxt][t] = pb[t * 64];
-        }
-        f32x16 acc[QW];
-#pragma unroll
-        for (int g = 0; g < QW; ++g) {
-#pragma unroll
-          for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
-#pragma unroll
-          for (int t = 0; t <= ND; ++t) acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cur][t], bqh[g][t], acc[g], 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < QW; ++g) {
-          if (__any(b == self_blk[g]) || b == NB - 1) {
-            const unsigned km = (b == self_blk[g] ? self_bit[g] : 0u) | (b == NB - 1 ? ~tail_vm & 0xffffu : 0u);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[g][e] = ((km >> e) & 1u) ? INFINITY : acc[g][e];
-          }
-#pragma unroll
-          for (int e = 0; e < 16; ++e) {
-            const unsigned key = (__float_as_uint(acc[g][e]) & keep) | j;
-            mn[g][u][e] = key < mn[g][u][e] ? key : mn[g][u][e];
-          }
-        }
-        ++j;
+      for (int t4 = 0; t4 < SMP_WAVES; ++t4) {
+        sample16_tile<ND, QW, false>(&stage[buf][t4][lane], bqh, mn[t4 % NSET], keep, (unsigned)(i0 + t4),
+                                     bf + t4 * bstride, (int)NB, self_blk, self_bit, tail_vm);
+        // two tiles in flight at most (fragments + accumulators of a third do not fit 256 registers: hipcc spilled)
+        if (t4 % 2 == 1) __builtin_amdgcn_sched_barrier(0);
       }
+    } else {
+#pragma unroll
+      for (int t4 = 0; t4 < SMP_WAVES; ++t4)
+        if (i0 + t4 < nt)
+          sample16_tile<ND, QW, true>(&stage[buf][t4][lane], bqh, mn[t4 % NSET], keep, (unsigned)(i0 + t4),
+                                      bf + t4 * bstride, (int)NB, self_blk, self_bit, tail_vm);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's tile of the next round is in LDS
+    __syncthreads();
   }
 #pragma unroll
   for (int g = 0; g < QW; ++g) {
@@ -854,7 +916,7 @@ __global__ __launch_bounds__(64) void knn_sample16_kernel(
         for (int jj = 0; jj < 4; ++jj) {
           u32x4 v;
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = mn[g][u][4 * jj + i];
+          for (int i = 0; i < 4; ++i) v[i] = mn[u][g][4 * jj + i];
           dst[u * 8 + jj] = v;
         }
     }
@@ -978,10 +1040,6 @@ __device__ __forceinline__ void wavebufc_flush(WaveBufC &wb, const float *__rest
   __builtin_amdgcn_wave_barrier();
   wb.n = 0;
 }
-
-#define CC_KNN_GLDS16(src, dst)                                                             \
-  __builtin_amdgcn_global_load_lds((const void __attribute__((address_space(1))) *)(src),   \
-                                   (void __attribute__((address_space(3))) *)(dst), 16, 0, 0)
 
 // the passing pairs of one 32 x 32 tile (acc = coarse distance − threshold: sign bit set = pass) as a lane mask:
 // bit (15 − e) = pair (this lane's query, candidate entry e) passes; 0 for the whole wave when the tile is rejected
@@ -1767,9 +1825,9 @@ static int run_select(int NG, const SelectArgs &a, int KP, int CAP, int S, int64
 
 static int run_sample16(int ND, int NSET, int QW, const h8 *P16, const SelectArgs &a, const unsigned *maxnorm_bits, float s,
                         int S, int64_t NBs, int bstride, unsigned *out_key) {
-  const int64_t nwaves = ceil_div(a.n_q, 32 * QW) * S;
+  const int64_t nwaves = ceil_div(a.n_q, 32 * QW * SMP_WAVES) * S;   // workgroups of SMP_WAVES waves
 #define CC_SMP16(NDV, NS, QWV)                                                                                    \
-  hipLaunchKernelGGL((knn_sample16_kernel<NDV, NS, QWV>), dim3((unsigned)nwaves), dim3(64), 0, stream(), P16, a.norms, \
+  hipLaunchKernelGGL((knn_sample16_kernel<NDV, NS, QWV>), dim3((unsigned)nwaves), dim3(64 * SMP_WAVES), 0, stream(), P16, a.norms, \
                      maxnorm_bits, a.x, a.mu, a.N, a.d, a.NB, a.q_begin, a.n_q, a.include_self, s, S, NBs, bstride, out_key)
 #define CC_SMP16_ND(NS, QWV)                                                                                      \
   switch (ND) {                                                                                                   \
