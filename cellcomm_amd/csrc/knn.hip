@@ -73,12 +73,34 @@ __global__ void knn_colsum_kernel(const float *__restrict__ x, int64_t N, int d,
   for (; i < hi; ++i) s += (double)x[i * d + c];
   partial[(int64_t)blockIdx.x * d + c] = s;
 }
+// One workgroup: MEAN_PARTS groups of threads each add a fixed quarter of the partial sums of their column (four loads in
+// flight), the first group adds the four in order.  (Round 4: one dependent chain of 2048 loads per column took 76 µs,
+// 2.5 % of a 100k-query search.)  The order of the sum is fixed by the constants, not by the launch.
+constexpr int MEAN_PARTS = 4;   // x round_up(d, 64) <= 192 threads: one workgroup
+static_assert(MEAN_BLOCKS % (MEAN_PARTS * 4) == 0, "whole groups of four per part");
 __global__ void knn_mean_kernel(const double *__restrict__ partial, int64_t N, int d, float *__restrict__ mu) {
-  const int c = threadIdx.x;
-  if (c >= d) return;
-  double s = 0.0;
-  for (int b = 0; b < MEAN_BLOCKS; ++b) s += partial[(int64_t)b * d + c];
-  mu[c] = (float)(s / (double)N);
+  __shared__ double part_sum[MEAN_PARTS][132];
+  const int c = threadIdx.x, part = threadIdx.y;
+  if (c < d) {
+    constexpr int PER = MEAN_BLOCKS / MEAN_PARTS;
+    const double *p = partial + (int64_t)part * PER * d + c;
+    double s = 0.0;
+    for (int b = 0; b < PER; b += 4) {
+      const double v0 = p[(int64_t)b * d], v1 = p[(int64_t)(b + 1) * d], v2 = p[(int64_t)(b + 2) * d], v3 = p[(int64_t)(b + 3) * d];
+      s += v0;
+      s += v1;
+      s += v2;
+      s += v3;
+    }
+    part_sum[part][c] = s;
+  }
+  __syncthreads();
+  if (part == 0 && c < d) {
+    double s = 0.0;
+#pragma unroll
+    for (int q = 0; q < MEAN_PARTS; ++q) s += part_sum[q][c];
+    mu[c] = (float)(s / (double)N);
+  }
 }
 
 // the one expression used everywhere for a centred coordinate (so duplicate rows stay duplicates)
@@ -940,8 +962,29 @@ __global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const unsigned 
   for (int j = 0; j < MAXR; ++j) key[j] = j < nreg ? skey[ql * n + j * 64 + lane] : 0xffffffffu;
   // only the distance bits order the keys (bit 31 is clear, the low SKEY_BITS are the tile index): 18 steps; keys
   // that agree with the m-th smallest in those bits are all taken
-  unsigned prefix = 0;
-  for (int bit = 30; bit >= SKEY_BITS; --bit) {
+  // (round 4) The bisection starts at the highest bit in which two real keys differ: the bits above it are the same in
+  // every real key, hence in the m-th smallest — the steps it would spend on them can only copy them (a common 1: no
+  // key lies under the trial value; a common 0: all do).  Slot minima of one query lie within a few binades, so a third
+  // of the 18 steps goes.  Fewer than m real keys: the m-th smallest is not a distance, T = +inf as before.
+  unsigned k_or = 0u, k_and = 0x7fffffffu;
+  int n_real = 0;
+#pragma unroll
+  for (int j = 0; j < MAXR; ++j)
+    if (j < nreg) {
+      const bool real = key[j] < 0x7f800000u;
+      k_or |= real ? key[j] : 0u;
+      k_and &= real ? key[j] : 0x7fffffffu;
+      n_real += __builtin_popcountll(__ballot(real));
+    }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) {
+    k_or |= __shfl_xor(k_or, o);
+    k_and &= __shfl_xor(k_and, o);
+  }
+  const unsigned differ = (k_or ^ k_and) & ~SKEY_MASK;
+  const int top = differ ? 31 - __builtin_clz(differ) : SKEY_BITS - 1;   // wave-uniform
+  unsigned prefix = n_real >= m ? (k_and & ~((2u << top) - 1u)) : 0x7f800000u;
+  for (int bit = n_real >= m ? top : -1; bit >= SKEY_BITS; --bit) {
     const unsigned trial = prefix | ((1u << bit) - 1u);
     int c = 0;
 #pragma unroll
@@ -2056,7 +2099,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
     const int mean_threads = (int)round_up(d, 64);
     hipLaunchKernelGGL(knn_colsum_kernel, dim3(MEAN_BLOCKS), dim3(mean_threads), 0, stream(), d_x, N, d,
                        partial.as<double>());
-    hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(mean_threads), 0, stream(), partial.as<double>(), N, d,
+    hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(mean_threads, MEAN_PARTS), 0, stream(), partial.as<double>(), N, d,
                        mu.as<float>());
     hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, stream(), d_x,
                        mu.as<float>(), N, d, norms.as<float>(), maxn.as<unsigned>());
