@@ -637,7 +637,7 @@ using namespace cc;
 
 extern "C" {
 
-int cc_version(void) { return 105; }   // 105: CC_KNN_OPT_COLLECT_GROUPS, pageable kNN results through a pinned bounce buffer, fp32 half-height tail tiles; 104: cc_encoder_batch, rows per pass chosen from the layer widths; 103: NULL handles / buffers refused, sparse passes, wrapped indptr checked end to end (102: cc_shutdown, kNN workspace handles)
+int cc_version(void) { return 106; }   // 106: CC_KNN_OPT_COLLECT_NORM_FORM; 105: CC_KNN_OPT_COLLECT_GROUPS, pageable kNN results through a pinned bounce buffer, fp32 half-height tail tiles; 104: cc_encoder_batch, rows per pass chosen from the layer widths; 103: NULL handles / buffers refused, sparse passes, wrapped indptr checked end to end (102: cc_shutdown, kNN workspace handles)
 const char *cc_last_error(void) { return g_err.c_str(); }
 
 int cc_device_count(void) {

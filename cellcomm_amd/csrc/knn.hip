@@ -682,12 +682,14 @@ __device__ __forceinline__ h8 panel16_unit(const float *__restrict__ x, const fl
 }
 
 // P16[((b·(ND+1) + t)·64 + lane)] (16-byte units): candidate 32b + (lane&31), lane half = lane>>5
+// ncs[i] = s²·‖c_i − μ‖² for i < N, 0 behind (n_ncs floats): the candidates' norms as the accumulator-form collect reads them
 __global__ void knn_pack16_kernel(const float *__restrict__ x, const float *__restrict__ mu,
                                   const float *__restrict__ norms, int64_t N, int d, int ND, int64_t NB, float s,
-                                  h8 *__restrict__ P16) {
+                                  h8 *__restrict__ P16, float *__restrict__ ncs, int64_t n_ncs) {
   const int NT = ND + 1;
   const int64_t total = NB * NT * 64;
   const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (f < n_ncs) ncs[f] = f < N ? norms[f] * (s * s) : 0.f;
   if (f >= total) return;
   const int lane = f & 63;
   const int t = (int)((f >> 6) % NT);
@@ -1175,16 +1177,27 @@ __device__ __forceinline__ void knn_stage_barrier() {
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 }
-template <int ND>
+// CN (round 4, late): the candidates' norms enter through the accumulator instead of a K-step of their own — the
+// first MFMA of a tile takes C = s²‖c−μ‖² (16 fp32 per lane, read from a 1 KiB norm row of the stage: all lanes of a
+// half read the same 16 bytes), the tile is ND MFMAs instead of ND + 1 (4 instead of 5 at d = 64), and a pair passes
+// when accumulator < Ts − s²‖q−μ‖² (one value per lane).  That comparison has no one-instruction sign form, so CN is
+// the kernel of the rare-hit shapes only: a v_min3 tree over the tiles of a block pair and ONE compare + ballot reject
+// it (the same count as the v_or3 tree of the K-step form); a tile with a hit pays 16 subtractions first.
+// NW = waves per workgroup, CBM = stage length multiplier: the product runs NW = 4 (three workgroups per CU, each with
+// its own stage ring), CBM = 1.  ONE 12-wave workgroup per CU (768 queries share every candidate stage: a third of the
+// LDS-DMA requests and panel bytes per MFMA), with stages of 2 or 4 blocks, was built on these parameters, is bit-identical
+// and measured null to slower at every shape (tools/experiments/knn_collect_12waves.patch has its launcher and options).
+template <int ND, bool CN = false, int NW = 4, int CBM = 1>
 struct C16C {
-  static constexpr int CB = ND == 1 ? 4 : ND == 2 ? 4 : ND == 4 ? 2 : 1;   // candidate blocks per stage
-  static constexpr int HU = (ND + 1) * 64;                                  // hi + norm units (16 B) of a block
-  static constexpr int STAGE_U = CB * HU;
-  static constexpr int NU = CB * (ND + 1);                                  // 64-lane unit rows (1 KiB) per stage
-  static constexpr int DPS = (NU + 3) / 4;                                  // most DMA instructions a wave issues per stage
+  static constexpr int CB = (ND == 1 ? 4 : ND == 2 ? 4 : ND == 4 ? 2 : 1) * CBM;   // candidate blocks per stage
+  static constexpr int TU = CN ? ND : ND + 1;                               // unit rows of a block in the stage: hi (+ norm K-step)
+  static constexpr int HU = TU * 64;                                        // their 16-byte units
+  static constexpr int NU = CB * TU + (CN ? 1 : 0);                         // 64-lane unit rows (1 KiB) per stage; CN: the last one = fp32 norms
+  static constexpr int STAGE_U = NU * 64;
+  static constexpr int DPS = (NU + NW - 1) / NW;                            // most DMA instructions a wave issues per stage
   static_assert(CB <= C16C_PAD_BLOCKS, "panel padding");
   static constexpr size_t lds_bytes() {
-    return sizeof(h8) * C16C_NSTAGE * STAGE_U + (sizeof(unsigned) + sizeof(int)) * 4 * COL_WB;
+    return sizeof(h8) * C16C_NSTAGE * STAGE_U + (sizeof(unsigned) + sizeof(int)) * NW * COL_WB;
   }
 };
 
@@ -1208,18 +1221,28 @@ __device__ __forceinline__ unsigned collect16c_or(const f32x16 &acc) {
   return o;
 }
 
-template <int ND, int QW>
-__global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
+// lane minimum of the 16 accumulators of a tile
+__device__ __forceinline__ float collect16c_min(const f32x16 &acc) {
+  float m = fminf(fminf(acc[0], acc[1]), acc[2]);
+#pragma unroll
+  for (int e = 3; e < 15; e += 2) m = fminf(fminf(m, acc[e]), acc[e + 1]);
+  return fminf(m, acc[15]);
+}
+
+template <int ND, int QW, bool CN, int NW, int CBM>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void knn_collect16c_kernel(
     const h8 *__restrict__ P16, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
     const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d, int NB, int64_t q_begin,
     int64_t n_q, int include_self, const float *__restrict__ T, float s, int S, int NBs, int cap,
     u64 *__restrict__ buf, int *__restrict__ cursor, int min_first) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  using C_ = C16C<ND>;
+  using C_ = C16C<ND, CN, NW, CBM>;
   constexpr int NT = ND + 1;                 // units per candidate block in the panel
+  constexpr int TU = C_::TU;                 // unit rows of a block that reach the stage (CN: without the norm K-step)
   constexpr int CB = C_::CB, HU = C_::HU, STAGE_U = C_::STAGE_U, NU = C_::NU, DPS = C_::DPS, NSTAGE = C16C_NSTAGE;
   constexpr int QPW = 32 * QW;               // queries per wave
-  constexpr int PB = CB >= 2 ? 2 : 1;        // blocks handled (and parked) together: PB * QW <= 4 tiles = the 64 mask bits of a lane
+  constexpr int CBH = CB / CBM;              // blocks worked off together (= CB unless the stage is stretched)
+  constexpr int PB = CBH >= 2 ? 2 : 1;       // blocks handled (and parked) together: PB * QW <= 4 tiles = the 64 mask bits of a lane
   h8 *stage = reinterpret_cast<h8 *>(smem);  // [NSTAGE][STAGE_U], then the 4 parking buffers
 
   const int tile = (int)(blockIdx.x / (unsigned)S);
@@ -1231,19 +1254,39 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
   const int r = lane & 31, h = lane >> 5;
   const float s2 = s * s;
   const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
-  const int64_t q0 = (int64_t)tile * (4 * QPW) + wave * QPW;
+  const int64_t q0 = (int64_t)tile * (NW * QPW) + wave * QPW;
   const int nstages = (b_hi - b_lo + CB - 1) / CB;
 
-  // DMA: unit rows u = wave, wave + 4, .. < NU of a stage; source = running wave-uniform pointer + lane * 16
-  const int my_dps = (NU - wave + 3) / 4;    // wave-uniform, DPS or DPS - 1
-  const char *gsrc = reinterpret_cast<const char *>(P16 + (int64_t)b_lo * (NT * 64)) + wave * 1024;
+  // DMA: unit rows u = wave, wave + 4, .. < NU of a stage; source = running wave-uniform pointer + lane * 16.
+  // CN: stage row u < CB·ND is panel row (u / ND)·NT + u % ND of the stage's first block (the norm K-steps stay
+  // behind), the last row = 1 KiB of ncs from the stage's first candidate on (8 blocks' worth, CB of them used)
+  const int my_dps = (NU - wave + NW - 1) / NW;   // wave-uniform, DPS or DPS - 1
+  const char *gsrc = reinterpret_cast<const char *>(P16 + (int64_t)b_lo * (NT * 64)) + (CN ? 0 : wave * 1024);
+  // (the fp32 norms sit behind the panel and its padding blocks in the same allocation: knn_pack16_kernel)
+  const char *nsrc = CN ? reinterpret_cast<const char *>(P16 + (int64_t)(NB + C16C_PAD_BLOCKS) * (NT * 64)) + (int64_t)b_lo * 128
+                        : nullptr;
   const unsigned voff = (unsigned)lane * 16u;
+  int roff[CN ? DPS : 1];                    // CN: wave-uniform byte offsets of this wave's rows inside the stage's panel slice
+  if constexpr (CN) {
+#pragma unroll
+    for (int i = 0; i < DPS; ++i) {
+      const int u = wave + NW * i;
+      roff[i] = ((u / ND) * NT + u % ND) * 1024;
+    }
+  }
   auto issue = [&](int slot) {
 #pragma unroll
     for (int i = 0; i < DPS; ++i)
-      if (wave + 4 * i < NU)   // wave-uniform
-        CC_KNN_GLDS16(gsrc + i * 4096 + voff, stage + (slot * STAGE_U + (wave + 4 * i) * 64));
-    gsrc += NU * 1024;
+      if (wave + NW * i < NU) {   // wave-uniform
+        if constexpr (CN) {
+          if (wave + NW * i == NU - 1) CC_KNN_GLDS16(nsrc + voff, stage + (slot * STAGE_U + (NU - 1) * 64));
+          else CC_KNN_GLDS16(gsrc + roff[i] + voff, stage + (slot * STAGE_U + (wave + NW * i) * 64));
+        } else {
+          CC_KNN_GLDS16(gsrc + i * (NW * 1024) + voff, stage + (slot * STAGE_U + (wave + NW * i) * 64));
+        }
+      }
+    if constexpr (CN) { gsrc += CB * NT * 1024; nsrc += CB * 128; }
+    else gsrc += NU * 1024;
   };
   // wait until at most `keep` of this wave's stages are still in flight (a stage = my_dps instructions)
   auto wait_stages = [&](bool counted) {
@@ -1255,7 +1298,8 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
   for (int p = 0; p < NSTAGE - 1; ++p)
     if (p < nstages) issue(p);   // under the set-up below
 
-  h8 bqh[QW][ND + 1];
+  h8 bqh[QW][TU];
+  float thr[QW];   // CN: Ts − s²‖q−μ‖², a pair passes when its accumulator is below
   int self_blk[QW];
   unsigned self_bit[QW];
 #pragma unroll
@@ -1266,14 +1310,20 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
 #pragma unroll
     for (int t = 0; t < ND; ++t)
       bqh[g][t] = panel16_unit(x, mu, norms, q, qvalid, d, ND, t, h, -2.0f * s, s2 * (1.0f / 256.0f), true);
-    // norm slot = s²‖q−μ‖² − Ts: the accumulator becomes (coarse distance − threshold), see the bound above
+    // norm slot = s²‖q−μ‖² − Ts: the accumulator becomes (coarse distance − threshold), see the bound above.
+    // CN: the same value, negated, is the lane's threshold (an invalid query has zero operands: its accumulators are the
+    // candidates' norms >= 0 and never fall below −1)
+    if constexpr (!CN) {
 #pragma unroll
-    for (int j = 0; j < 8; ++j) bqh[g][ND][j] = (_Float16)0.f;
+      for (int j = 0; j < 8; ++j) bqh[g][ND][j] = (_Float16)0.f;
+    }
+    if constexpr (CN) thr[g] = -1.0f;
     if (qvalid) {
       const float nq = norms[q];
       const float Ts = fminf((T[ql] + 1.953125e-3f * (nq + __uint_as_float(maxnorm_bits[0]))) * s2 + (float)d * 3.0517578125e-5f,
                              12582912.0f);
-      bqh[g][ND] = query_norm_unit((nq * s2 - Ts) * (1.0f / 256.0f), h);
+      if constexpr (CN) thr[g] = Ts - nq * s2;
+      else bqh[g][ND] = query_norm_unit((nq * s2 - Ts) * (1.0f / 256.0f), h);
     }
     self_blk[g] = -1;
     self_bit[g] = 0;
@@ -1291,7 +1341,7 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
   const int tail_blk = (N & 31) ? NB - 1 : 0x7fffffff;   // the partly filled last block, if any
   WaveBufC wb;
   wb.cand = reinterpret_cast<unsigned *>(smem + sizeof(h8) * NSTAGE * STAGE_U) + wave * COL_WB;
-  wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * NSTAGE * STAGE_U + sizeof(unsigned) * 4 * COL_WB) + wave * COL_WB;
+  wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * NSTAGE * STAGE_U + sizeof(unsigned) * NW * COL_WB) + wave * COL_WB;
   wb.n = 0;
 
   unsigned tail_vm = 0xffffu;
@@ -1308,31 +1358,77 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     // the slot written now was read one stage ago, and every wave is past that barrier
     const bool ahead = st + NSTAGE - 1 < nstages;
     if (ahead) issue(slot >= 1 ? slot - 1 : NSTAGE - 1);   // (slot + NSTAGE - 1) % NSTAGE
-    const h8 *sbuf = stage + slot * STAGE_U + lane;
-    h8 ah[CB][ND + 1];
+    // (CBM > 1: the stage is worked off in CBM parts of CBH blocks, so that only a part's fragments are in registers)
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb)
+    for (int hf = 0; hf < CBM; ++hf) {
+    const h8 *sbuf = stage + slot * STAGE_U + hf * CBH * HU + lane;
+    h8 ah[CBH][TU];
 #pragma unroll
-      for (int t = 0; t <= ND; ++t) ah[cb][t] = sbuf[cb * HU + t * 64];
-    const int b0 = b_lo + st * CB;
+    for (int cb = 0; cb < CBH; ++cb)
+#pragma unroll
+      for (int t = 0; t < TU; ++t) ah[cb][t] = sbuf[cb * HU + t * 64];
+    // CN: what the accumulators of block cb start from — entry e of lane (r, h) is candidate (e & 3) + 8 (e >> 2) + 4 h:
+    // four runs of four consecutive floats of the block's 32 (every lane of a half reads the same 16 bytes)
+    const f32x4 *nbuf = reinterpret_cast<const f32x4 *>(stage + slot * STAGE_U + (NU - 1) * 64) + hf * CBH * 8 + h;
+    // (read inside the path that uses them: hoisted beside the fragment reads they stay live across the masked path
+    // and the kernel spills)
+    auto cinit = [&](int cb) {
+      f32x16 c;
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const f32x4 v = nbuf[cb * 8 + 2 * gq];
+        c[4 * gq] = v[0]; c[4 * gq + 1] = v[1]; c[4 * gq + 2] = v[2]; c[4 * gq + 3] = v[3];
+      }
+      return c;
+    };
+    const int b0 = b_lo + st * CB + hf * CBH;
     // wave-uniform: no block of this stage needs a mask (own queries, padding rows) and all of them lie in the range
-    const bool plain = b0 + CB <= b_hi && (b0 > sp_hi || b0 + CB <= sp_lo) && b0 + CB <= tail_blk;
+    const bool plain = b0 + CBH <= b_hi && (b0 > sp_hi || b0 + CBH <= sp_lo) && b0 + CBH <= tail_blk;
     if (plain) {
 #pragma unroll
-      for (int pb = 0; pb < CB; pb += PB) {
+      for (int pb = 0; pb < CBH; pb += PB) {
         f32x16 acc[PB][QW];
 #pragma unroll
-        for (int c = 0; c < PB; ++c)
+        for (int c = 0; c < PB; ++c) {
+          f32x16 c0;
+          if constexpr (CN) c0 = cinit(pb + c);
 #pragma unroll
           for (int g = 0; g < QW; ++g) {
+            if constexpr (CN) {
+              acc[c][g] = c0;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[c][g][e] = 0.f;
+              for (int e = 0; e < 16; ++e) acc[c][g][e] = 0.f;
+            }
 #pragma unroll
-            for (int t = 0; t <= ND; ++t)
+            for (int t = 0; t < TU; ++t)
               acc[c][g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[pb + c][t], bqh[g][t], acc[c][g], 0, 0, 0);
           }
+        }
         unsigned long long m64 = 0;
-        if (min_first) {
+        if constexpr (CN) {
+          float mn[PB][QW];
+          bool hit = false;
+#pragma unroll
+          for (int g = 0; g < QW; ++g) {
+            float mg = 3.0e38f;
+#pragma unroll
+            for (int c = 0; c < PB; ++c) { mn[c][g] = collect16c_min(acc[c][g]); mg = fminf(mg, mn[c][g]); }
+            hit |= mg < thr[g];
+          }
+          if (__any(hit)) {
+#pragma unroll
+            for (int c = 0; c < PB; ++c)
+#pragma unroll
+              for (int g = 0; g < QW; ++g)
+                if (__any(mn[c][g] < thr[g])) {
+                  f32x16 df;
+#pragma unroll
+                  for (int e = 0; e < 16; ++e) df[e] = acc[c][g][e] - thr[g];
+                  m64 |= (unsigned long long)collect16c_signs(df) << (16 * (c * QW + g));
+                }
+          }
+        } else if (min_first) {
           unsigned o[PB][QW], oall = 0;
 #pragma unroll
           for (int c = 0; c < PB; ++c)
@@ -1356,29 +1452,40 @@ __global__ __launch_bounds__(256, 3) void knn_collect16c_kernel(
     } else {
       unsigned long long m64 = 0;
 #pragma unroll
-      for (int cb = 0; cb < CB; ++cb) {
+      for (int cb = 0; cb < CBH; ++cb) {
         const int b = b0 + cb;
         if (b < b_hi) {   // workgroup-uniform
           f32x16 acc[QW];
+          f32x16 c0;
+          if constexpr (CN) c0 = cinit(cb);
 #pragma unroll
           for (int g = 0; g < QW; ++g) {
+            if constexpr (CN) {
+              acc[g] = c0;
+            } else {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+              for (int e = 0; e < 16; ++e) acc[g][e] = 0.f;
+            }
 #pragma unroll
-            for (int t = 0; t <= ND; ++t)
+            for (int t = 0; t < TU; ++t)
               acc[g] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[cb][t], bqh[g][t], acc[g], 0, 0, 0);
+            if constexpr (CN) {   // the sign form of the masked path (rare: own queries, the last block, the end of the range)
+#pragma unroll
+              for (int e = 0; e < 16; ++e) acc[g][e] -= thr[g];
+            }
           }
 #pragma unroll
           for (int g = 0; g < QW; ++g)
             m64 |= (unsigned long long)collect16c_mask(acc[g], b, NB, self_blk[g], self_bit[g], tail_vm, min_first)
                    << (16 * ((PB == 2 ? (cb & 1) : 0) * QW + g));
         }
-        if (PB == 1 || (cb & 1) || cb == CB - 1) {   // the tiles of PB candidate blocks are parked together
+        if (PB == 1 || (cb & 1) || cb == CBH - 1) {   // the tiles of PB candidate blocks are parked together
           collect16c_park<QW>(m64, b - (PB == 2 ? (cb & 1) : 0), wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
           m64 = 0;
         }
       }
     }
+    }   // hf
     // the next stage's data must have landed (in the tail fewer stages are in flight than the count assumes)
     wait_stages(ahead);
     knn_stage_barrier();
@@ -1806,6 +1913,7 @@ struct KnnWorkspace {
   bool use_fp64_prefilter = true;          // stage 3: float64 matrix-core prefilter in front of the exact scan
   bool use_coarse_collect = true;          // stage 1b collect on the fp16 tile + direct fp32 re-evaluation of the parked pairs; off: fp32 list collect
   int collect_qw = 0;                      // 0 = chosen per call; 1 / 2 = 32-query groups per wave of the coarse collect
+  int collect_norm_form = 0;               // 0 = chosen per call; 1 = norm K-step (sign test); 2 = norms through the accumulator
   int collect_splits = 0;                  // 0 = chosen per call; > 0 = forced (tools/knn_split_sweep.sh)
   int sample_splits = 0;                   // same for the candidate ranges of the fp16 sample pass
   int sample_stride = 0;                   // 0 = CC_KNN_SAMPLE; > 0 = every n-th candidate block is sampled
@@ -1911,16 +2019,28 @@ static int run_collect(int NG, const SelectArgs &a, const float *T, int S, int64
   return CC_OK;
 }
 
-static int run_collect16c(int ND, int QW, const h8 *P16, const SelectArgs &a, const unsigned *maxnorm_bits, const float *T,
-                          float s, int S, int64_t NBs, int cap, u64 *buf, int *cursor) {
+// expected pairs of a 32 x 32 tile under the threshold: ~cap / 4 collected per query out of N candidates
+static bool collect16c_hits_are_rare(int cap, int64_t N) { return (1024.0 * (double)(cap / 4) / (double)N) < 0.5; }
+
+// norm_form: 0 = the norms ride in a K-step of their own (sign test), 1 = through the accumulator (C16C CN)
+static int run_collect16c(int ND, int QW, int norm_form, const h8 *P16, const SelectArgs &a,
+                          const unsigned *maxnorm_bits, const float *T, float s, int S, int64_t NBs, int cap, u64 *buf,
+                          int *cursor) {
   const int64_t nwg = ceil_div(a.n_q, 128 * QW) * S;
-  // expected pairs of a 32 x 32 tile under the threshold: ~cap / 4 collected per query out of N candidates
-  const int min_first = (1024.0 * (double)(cap / 4) / (double)a.N) < 0.5 ? 1 : 0;
-#define CC_COL16C(NDV, QWV)                                                                                          \
-  hipLaunchKernelGGL((knn_collect16c_kernel<NDV, QWV>), dim3((unsigned)nwg), dim3(256),                              \
-                     C16C<NDV>::lds_bytes(), stream(),                                                                \
-                     P16, a.norms, maxnorm_bits, a.x, a.mu, a.N, a.d, (int)a.NB, a.q_begin, a.n_q, a.include_self, T, s, S, \
-                     (int)NBs, cap, buf, cursor, min_first)
+  const int min_first = collect16c_hits_are_rare(cap, a.N) ? 1 : 0;
+#define CC_COL16C_L(NDV, QWV, CNV, NWV, CBMV, MF)                                                                    \
+  do {                                                                                                               \
+    const size_t lds = C16C<NDV, CNV, NWV, CBMV>::lds_bytes();                                                       \
+    if (lds > 64 * 1024)                                                                                             \
+      CC_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(knn_collect16c_kernel<NDV, QWV, CNV, NWV, CBMV>),    \
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                            \
+    hipLaunchKernelGGL((knn_collect16c_kernel<NDV, QWV, CNV, NWV, CBMV>), dim3((unsigned)nwg), dim3(64 * NWV), lds,   \
+                       stream(), P16, a.norms, maxnorm_bits, a.x, a.mu, a.N, a.d, (int)a.NB, a.q_begin, a.n_q,       \
+                       a.include_self, T, s, S, (int)NBs, cap, buf, cursor, MF);                                     \
+  } while (0)
+#define CC_COL16C(NDV, QWV)                                      \
+  if (norm_form) CC_COL16C_L(NDV, QWV, true, 4, 1, 1);           \
+  else CC_COL16C_L(NDV, QWV, false, 4, 1, min_first)
   if (QW == 2) {
     switch (ND) {
       case 1: CC_COL16C(1, 2); break;
@@ -1937,6 +2057,7 @@ static int run_collect16c(int ND, int QW, const h8 *P16, const SelectArgs &a, co
       default: CC_REQUIRE(false, "knn: no coarse fp16 collect kernel for ND=%d", ND);
     }
   }
+#undef CC_COL16C_L
 #undef CC_COL16C
   CC_HIP(hipGetLastError());
   return CC_OK;
@@ -2149,10 +2270,14 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
       }
       if (scale16 > 0.f) {
         // (+ C16C_PAD_BLOCKS blocks of "no candidate" behind the panel: the collect's stages are loaded whole)
+        // (and, behind them, the scaled norms once more as plain fp32, + 8 blocks: the accumulator form of the collect
+        // loads them 1 KiB at a time)
         const int64_t units = (NB + C16C_PAD_BLOCKS) * (ND16 + 1) * 64;
-        if ((rc = P16.alloc(sizeof(h8) * (size_t)units))) return rc;
+        const int64_t n_ncs = (NB + C16C_PAD_BLOCKS + 8) * 32;
+        if ((rc = P16.alloc(sizeof(h8) * (size_t)units + sizeof(float) * (size_t)n_ncs))) return rc;
         hipLaunchKernelGGL(knn_pack16_kernel, dim3((unsigned)ceil_div(units, 256)), dim3(256), 0, stream(), d_x,
-                           mu.as<float>(), norms.as<float>(), N, d, ND16, NB + C16C_PAD_BLOCKS, scale16, P16.as<h8>());
+                           mu.as<float>(), norms.as<float>(), N, d, ND16, NB + C16C_PAD_BLOCKS, scale16, P16.as<h8>(),
+                           reinterpret_cast<float *>(P16.as<h8>() + units), n_ncs);
       }
       // 1b-i: threshold from the sample (every SAMPLE-th candidate block)
       if (collect_all) {
@@ -2255,8 +2380,11 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
       if ((rc = ccur.alloc(sizeof(int) * (size_t)n_q))) return rc;
       CC_HIP(hipMemsetAsync(ccur.p, 0, sizeof(int) * (size_t)n_q, stream()));
       if (coarse) {
-        if ((rc = run_collect16c(ND16, QW, P16.as<h8>(), sa, maxn.as<unsigned>(), Tq.as<float>(), scale16, S, NBs, col_cap,
-                                 cbuf.as<u64>(), ccur.as<int>())))
+        // the accumulator form is the kernel of the rare-hit shapes (see C16C)
+        const int norm_form = ws.collect_norm_form == 0 ? (ND16 <= 4 && collect16c_hits_are_rare(col_cap, N) ? 1 : 0)
+                                                         : ws.collect_norm_form - 1;
+        if ((rc = run_collect16c(ND16, QW, norm_form, P16.as<h8>(), sa, maxn.as<unsigned>(), Tq.as<float>(),
+                                 scale16, S, NBs, col_cap, cbuf.as<u64>(), ccur.as<int>())))
           return rc;
         // The list holds exactly the pairs whose DIRECT fp32 distance is <= T (error ~d·2^-24 of the distance, far inside
         // the fp32 bound above); the certificate keeps the wider bound rounds 1-2 derived for the three-product tile,
@@ -2449,6 +2577,10 @@ int cc_knn_set_option(void *knn, int option, int value) {
     case CC_KNN_OPT_COLLECT_GROUPS:
       CC_REQUIRE(value >= 0 && value <= 2, "collect groups %d outside [0, 2]", value);
       ws->collect_qw = value;
+      break;
+    case CC_KNN_OPT_COLLECT_NORM_FORM:
+      CC_REQUIRE(value >= 0 && value <= 2, "collect norm form %d outside [0, 2]", value);
+      ws->collect_norm_form = value;
       break;
     case CC_KNN_OPT_SAMPLE_STRIDE:
       CC_REQUIRE(value >= 0 && value <= 64, "sample stride %d outside [0, 64]", value);

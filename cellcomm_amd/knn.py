@@ -91,6 +91,13 @@ def set_collect_groups(groups=0):
     _lib.check(_lib.lib().cc_knn_set_option(None, 10, int(groups)))
 
 
+def set_collect_norm_form(form=0):
+    """Tuning / test hook: how the coarse collect's tile takes the two norms — 1 = a K-step of their own (ND + 1
+    MFMAs, one-instruction sign test), 2 = through the accumulator (ND MFMAs, the kernel of the rare-hit shapes);
+    0 = chosen by the library.  Results never depend on it (CC_KNN_OPT_COLLECT_NORM_FORM)."""
+    _lib.check(_lib.lib().cc_knn_set_option(None, 11, int(form)))
+
+
 def use_fp64_prefilter(on):
     """Stage 3: narrow each uncertified query's candidates with a float64 matrix-core pass (default) before
     the exact evaluation, or scan all candidates; same results, different speed."""

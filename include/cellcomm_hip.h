@@ -212,6 +212,7 @@ int cc_knn_search_dev(void *knn, const float *dev_x, int64_t n_total, int d, int
 #define CC_KNN_OPT_SAMPLE_STRIDE 8     /* every n-th candidate block feeds the threshold; 0 = default   */
 #define CC_KNN_OPT_SAMPLE_GROUPS 9     /* 32-query groups per wave of the fp16 sample pass; 0 = per call */
 #define CC_KNN_OPT_COLLECT_GROUPS 10   /* 32-query groups per wave of the coarse collect (1, 2); 0 = per call    */
+#define CC_KNN_OPT_COLLECT_NORM_FORM 11 /* coarse collect tile: 1 = norms in a K-step of their own, 2 = through the accumulator (ABI v106); 0 = per call */
 /* None of the options changes a result bit (stage 2 certifies or stage 3 recomputes); only speed. */
 int cc_knn_set_option(void *knn, int option, int value);
 #define CC_KNN_STAT_FALLBACK_QUERIES 0  /* queries of the last search that stage 2 could not certify   */

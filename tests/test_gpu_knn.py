@@ -163,13 +163,15 @@ def test_coarse_and_fp32_list_collect_agree(hip, oracle_built, kind):
         x = rng.random((n, d), dtype=np.float32)
         x[:, ::2] *= 1e-6                                     # half the coordinates fall into the fp16 subnormal range
     want_i, want_d = ko.knn(x, k)
-    for coarse in (True, False):
+    for coarse, form in ((True, 1), (True, 2), (False, 0)):    # coarse tile with the norm K-step / norms through the accumulator; fp32 lists
         hipknn.use_coarse_collect(coarse)
+        hipknn.set_collect_norm_form(form)
         try:
             idx, dist = cc.knn_graph(x, k)
         finally:
             hipknn.use_coarse_collect(True)
-        assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (kind, coarse)
+            hipknn.set_collect_norm_form(0)
+        assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (kind, coarse, form)
 
 
 @pytest.mark.parametrize('n,d,k,dup', [(9000, 64, 15, True), (20011, 64, 50, False), (4100, 50, 15, True), (70000, 64, 15, False)])
@@ -198,6 +200,39 @@ def test_collect_groups_never_change_the_result(hip, oracle_built, n, d, k, dup)
                 for q, (wi, wd) in zip(picks, want):
                     assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0]), (groups, splits, int(q))
     finally:
+        hipknn.set_collect_groups(0)
+        hip.cc_knn_set_option(None, 5, 0)
+
+
+@pytest.mark.parametrize('n,d,k,dup', [(9000, 64, 15, True), (20011, 64, 50, False), (4100, 50, 15, True), (6007, 32, 15, True),
+                                       (5003, 16, 15, False), (3001, 3, 15, True), (70000, 64, 15, False)])
+def test_collect_norm_forms_never_change_the_result(hip, oracle_built, n, d, k, dup):
+    """The coarse collect's tile takes the two norms either in a K-step of their own (ND + 1 MFMAs, the pass test is the
+    accumulator's sign) or through the accumulator (ND MFMAs: C = the candidates' scaled norms, a pair passes below a
+    per-lane threshold; the library picks it when hits are rare).  Forced either way — every latent width's kernel
+    (ND = 1, 2, 4), one or two query groups, ranges that end inside a stage, the partly filled last block, own-query
+    blocks, duplicates — the lists are the oracle's.  n = 70000 is checked on sampled queries."""
+    rng = np.random.default_rng(n + 3 * d + k)
+    x = rng.random((n, d), dtype=np.float32)
+    if dup:
+        x[rng.choice(n, n // 20, replace=False)] = x[rng.choice(n, n // 20)]
+    picks = np.arange(n) if n <= 21000 else np.concatenate([rng.choice(n, 60, replace=False), [0, 31, 32, n - 1]])
+    want = [ko.knn(x, k, q_begin=int(q), n_q=1) for q in picks] if n > 21000 else None
+    if want is None:
+        want_i, want_d = ko.knn(x, k)
+    try:
+        for form, groups, splits in [(2, 0, 0), (2, 1, 0), (2, 2, 3), (2, 2, 7), (2, 1, 16), (1, 0, 0), (0, 0, 0)]:
+            hipknn.set_collect_norm_form(form)
+            hipknn.set_collect_groups(groups)
+            hip.cc_knn_set_option(None, 5, splits)
+            idx, dist = cc.knn_graph(x, k)
+            if want is None:
+                assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (form, groups, splits)
+            else:
+                for q, (wi, wd) in zip(picks, want):
+                    assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0]), (form, groups, splits, int(q))
+    finally:
+        hipknn.set_collect_norm_form(0)
         hipknn.set_collect_groups(0)
         hip.cc_knn_set_option(None, 5, 0)
 

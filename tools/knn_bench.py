@@ -25,6 +25,8 @@ if os.environ.get('CC_KNN_SAMPLE_GROUPS'):
     _lib.check(_lib.lib().cc_knn_set_option(None, 9, int(os.environ['CC_KNN_SAMPLE_GROUPS'])))
 if os.environ.get('CC_KNN_COLLECT_GROUPS'):
     _lib.check(_lib.lib().cc_knn_set_option(None, 10, int(os.environ['CC_KNN_COLLECT_GROUPS'])))
+if os.environ.get('CC_KNN_COLLECT_NORM_FORM'):
+    _lib.check(_lib.lib().cc_knn_set_option(None, 11, int(os.environ['CC_KNN_COLLECT_NORM_FORM'])))
 torch.manual_seed(20260105)   # the same points in every process: A/B runs compare like with like
 x = torch.rand((n, d), device='cuda'); torch.cuda.synchronize()
 knn_graph_device(x.data_ptr(), n, d, k, 0, nq)
