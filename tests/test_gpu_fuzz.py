@@ -37,17 +37,26 @@ def test_knn_random_shapes_and_regimes(hip, oracle_built):
         k = int(min(rng.choice([1, 2, 7, 15, 40, 100]), n - 1))
         include_self = bool(rng.integers(0, 2))
         x = _data(rng, n, d, kinds[case % len(kinds)])
-        idx, dist = cc.knn_graph(x, k, include_self)
+        form = (case // len(kinds)) % 3        # 0 = the library's choice, 1 = norm K-step, 2 = norms through the accumulator
+        hipknn.set_collect_norm_form(form)
+        try:
+            idx, dist = cc.knn_graph(x, k, include_self)
+        finally:
+            hipknn.set_collect_norm_form(0)
         wi, wd = ko.knn(x, k, include_self)
-        assert np.array_equal(idx, wi), (case, n, d, k, kinds[case % len(kinds)])
-        assert np.array_equal(dist, wd), (case, n, d, k, kinds[case % len(kinds)])
+        assert np.array_equal(idx, wi), (case, n, d, k, kinds[case % len(kinds)], form)
+        assert np.array_equal(dist, wd), (case, n, d, k, kinds[case % len(kinds)], form)
 
 
 def test_knn_large_regimes_sampled_route(hip, oracle_built):
     rng = np.random.default_rng(7)
     for kind in ['normal_big', 'lattice', 'clusters', 'huge']:
         x = _data(rng, 20000, 16, kind)
-        idx, dist = cc.knn_graph(x, 15)
+        hipknn.set_collect_norm_form(2 if kind in ('normal_big', 'clusters') else 1)
+        try:
+            idx, dist = cc.knn_graph(x, 15)
+        finally:
+            hipknn.set_collect_norm_form(0)
         for q in rng.choice(20000, 60, replace=False):
             wi, wd = ko.knn(x, 15, q_begin=int(q), n_q=1)
             assert np.array_equal(idx[q], wi[0]) and np.array_equal(dist[q], wd[0]), kind

@@ -46,21 +46,27 @@ while time.time() < t_end:
         n = int(rng.integers(2, 4000)); d = int(rng.choice([1, 2, 3, 5, 8, 16, 31, 64, 100, 132]))
         k = int(min(rng.choice([1, 2, 7, 15, 40, 100, 128]), n - 1)); inc = bool(rng.integers(0, 2)); kind = str(rng.choice(kinds))
         x = data(n, d, kind)
+        form = int(rng.integers(0, 3))                 # collect tile: the library's choice / norm K-step / norms through the accumulator
+        hipknn.set_collect_norm_form(form)
         idx, dist = cc.knn_graph(x, k, inc)
+        hipknn.set_collect_norm_form(0)
         wi, wd = ko.knn(x, k, inc)
         ok = np.array_equal(idx, wi) and np.array_equal(dist, wd)
-        desc = (what, n, d, k, inc, kind)
+        desc = (what, n, d, k, inc, kind, form)
     elif what == 'knn_big':
         n = int(rng.integers(8000, 60000)); d = int(rng.choice([3, 16, 32, 64])); k = int(rng.choice([1, 15, 50])); kind = str(rng.choice(kinds))
         x = data(n, d, kind)
         q0 = int(rng.integers(0, n // 2)); nq = int(rng.integers(1, n - q0))
         t = torch.from_numpy(x).cuda(); torch.cuda.synchronize()
+        form = int(rng.integers(0, 3))
+        hipknn.set_collect_norm_form(form)
         idx, dist = hipknn.knn_graph_device(t.data_ptr(), n, d, k, q_begin=q0, n_q=nq)
+        hipknn.set_collect_norm_form(0)
         ok = True
         for ql in rng.choice(nq, min(40, nq), replace=False):
             wi, wd = ko.knn(x, k, q_begin=q0 + int(ql), n_q=1)
             ok = ok and np.array_equal(idx[ql], wi[0]) and np.array_equal(dist[ql], wd[0])
-        desc = (what, n, d, k, kind, q0, nq, hipknn.last_fallback_count(), hipknn.last_full_scan_count())
+        desc = (what, n, d, k, kind, q0, nq, form, hipknn.last_fallback_count(), hipknn.last_full_scan_count())
     elif what == 'encoder':
         arch = str(rng.choice(['cont', 'cls'])); g = int(rng.integers(1, 3000)); e = int(rng.integers(1, 70)); n = int(rng.integers(1, 700))
         dtype = str(rng.choice(['f32', 'f16x2', 'f16']))
