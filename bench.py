@@ -563,15 +563,19 @@ def main():
             stat = ctypes.c_int64()
             _lib.check(_lib.lib().cc_knn_stat(None, 2, ctypes.byref(stat)))   # CC_KNN_STAT_SAMPLE_STRIDE of the last search
             stride = int(stat.value) or 8
-            executed = 16.0 * (nd + 1) * (1.0 + 1.0 / stride) / args.latent
+            _lib.check(_lib.lib().cc_knn_stat(None, 3, ctypes.byref(stat)))   # CC_KNN_STAT_COLLECT_NORM_FORM: 2 = the collect's tile has no norm K-step
+            collect_steps = nd if int(stat.value) == 2 else nd + 1
+            executed = 16.0 * (collect_steps + (nd + 1) / stride) / args.latent
             line['roofline_knn'] = {'kernel': 'knn_sample16 + knn_collect16c + knn_merge + knn_rerank (per step)',
                                     'bound': 'mfma', 'achieved': ktf, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': ktf / PEAK_F16_MFMA_TFLOPS, 'executed_fp16_tflops': executed * ktf,
                                     'ms_per_step': knn_ms, 'flop_per_step': knn_flop, 'traffic': None,
                                     'note': 'achieved = algorithmic 2*q*c*d FLOP / stage time; executed = x%.3f (one fp16 '
-                                            'product + norm step per pair: collect over all candidates, sample over every '
-                                            '%d-th block); parking and re-checking the passing pairs (VALU/LDS) shares '
-                                            'the time' % (executed, stride)}
+                                            'product per pair in %d MFMA K-steps of 16: collect over all candidates%s, sample '
+                                            'with the norm K-step over every %d-th block); parking and re-checking the passing '
+                                            'pairs (VALU/LDS) shares the time'
+                                            % (executed, collect_steps, ' with the norms through the accumulator' if collect_steps == nd else
+                                               ' incl. the norm K-step', stride)}
         gather = prof['gather']
         if gather['ms'] > 0:
             gbs = gather['work'] / (gather['ms'] * 1e-3) / 1e9

@@ -1921,6 +1921,7 @@ struct KnnWorkspace {
   int64_t last_fallback = 0;
   int64_t last_full_scan = 0;              // fallback queries that had to scan every candidate in float64 VALU
   int64_t last_sample_stride = 0;          // sampling stride of the last search that took route 1b with a sample (else 0)
+  int64_t last_norm_form = 0;              // tile of the last coarse collect: 1 = norm K-step, 2 = norms through the accumulator (0: no coarse collect ran)
   // pinned bounce buffer for results that go to PAGEABLE caller memory (copy_results)
   void *pin = nullptr;
   size_t pin_cap = 0;
@@ -2128,6 +2129,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
   ws.last_fallback = 0;
   ws.last_full_scan = 0;
   ws.last_sample_stride = 0;
+  ws.last_norm_form = 0;
   CC_REQUIRE(N > 0 && N < (int64_t)2147483000, "knn: n_total=%lld out of range", (long long)N);
   CC_REQUIRE(d >= 1 && d <= 132, "knn: d=%d unsupported (1..132)", d);
   CC_REQUIRE(k >= 1 && k <= 128, "knn: k=%d unsupported (1..128)", k);
@@ -2383,6 +2385,7 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
         // the accumulator form is the kernel of the rare-hit shapes (see C16C)
         const int norm_form = ws.collect_norm_form == 0 ? (ND16 <= 4 && collect16c_hits_are_rare(col_cap, N) ? 1 : 0)
                                                          : ws.collect_norm_form - 1;
+        ws.last_norm_form = norm_form + 1;
         if ((rc = run_collect16c(ND16, QW, norm_form, P16.as<h8>(), sa, maxn.as<unsigned>(), Tq.as<float>(),
                                  scale16, S, NBs, col_cap, cbuf.as<u64>(), ccur.as<int>())))
           return rc;
@@ -2598,6 +2601,7 @@ int cc_knn_stat(void *knn, int stat, int64_t *value) {
     case CC_KNN_STAT_FALLBACK_QUERIES: *value = ws->last_fallback; break;
     case CC_KNN_STAT_FULL_SCAN_QUERIES: *value = ws->last_full_scan; break;
     case CC_KNN_STAT_SAMPLE_STRIDE: *value = ws->last_sample_stride; break;
+    case CC_KNN_STAT_COLLECT_NORM_FORM: *value = ws->last_norm_form; break;
     default: CC_REQUIRE(false, "unknown kNN statistic %d", stat);
   }
   return CC_OK;

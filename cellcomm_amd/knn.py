@@ -112,6 +112,15 @@ def last_sample_stride():
     return int(out.value)
 
 
+def last_collect_norm_form():
+    """Tile of the last search's coarse collect: 1 = norm K-step, 2 = norms through the accumulator, 0 = no coarse
+    collect ran (small inputs, fp32 routes)."""
+    import ctypes
+    out = ctypes.c_int64()
+    _lib.check(_lib.lib().cc_knn_stat(None, 3, ctypes.byref(out)))
+    return int(out.value)
+
+
 def last_full_scan_count():
     """Uncertified queries of the last call that had to scan every candidate in float64."""
     return int(_lib.lib().cc_knn_last_full_scan_count())

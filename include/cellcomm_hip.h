@@ -218,6 +218,7 @@ int cc_knn_set_option(void *knn, int option, int value);
 #define CC_KNN_STAT_FALLBACK_QUERIES 0  /* queries of the last search that stage 2 could not certify   */
 #define CC_KNN_STAT_FULL_SCAN_QUERIES 1 /* of those, the ones that scanned ALL candidates in float64   */
 #define CC_KNN_STAT_SAMPLE_STRIDE 2     /* every n-th candidate block was sampled for the threshold (0: no sample pass) */
+#define CC_KNN_STAT_COLLECT_NORM_FORM 3  /* tile of the last coarse collect: 1 = norm K-step, 2 = accumulator form (0: none ran; ABI v106) */
 int cc_knn_stat(void *knn, int stat, int64_t *value);
 
 /* Shorthands (ABI v101) for options / statistics of the default workspace. */

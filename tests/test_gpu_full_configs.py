@@ -17,7 +17,7 @@ import pytest
 
 import cellcomm_amd as cc
 from cellcomm_amd import synth
-from cellcomm_amd.knn import knn_graph_device, last_fallback_count, last_full_scan_count
+from cellcomm_amd.knn import knn_graph_device, last_collect_norm_form, last_fallback_count, last_full_scan_count
 from oracle import encoder_oracle as eo
 from oracle import knn_oracle as ko
 
@@ -126,6 +126,7 @@ def full_config(n, g, e, k, dtype, seed, seams, report_name):
               'synth_s': round(t_synth, 2), 'encode_ms_one_call': round(t_enc * 1e3, 1),
               'encode_cells_per_s': round(n / t_enc), 'knn_ms_one_call_incl_copy_out': round(t_knn * 1e3, 1),
               'knn_fallback_queries': fallback, 'knn_full_scan_queries': full_scan,
+              'knn_collect_norm_form': last_collect_norm_form(),    # 2 = the accumulator form (the library's choice when hits are rare)
               'sampled_rows_max_rel_vs_oracle': rel, 'sampled_queries_bit_exact': len(picks),
               'device_GiB_used_after_encode': round((total_mem - free_after_encode) / 2**30, 2),
               'device_GiB_used_after_knn': round((total_mem - free_after_knn) / 2**30, 2),

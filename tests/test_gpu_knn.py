@@ -226,6 +226,8 @@ def test_collect_norm_forms_never_change_the_result(hip, oracle_built, n, d, k, 
             hipknn.set_collect_groups(groups)
             hip.cc_knn_set_option(None, 5, splits)
             idx, dist = cc.knn_graph(x, k)
+            ran = hipknn.last_collect_norm_form()
+            assert ran == form if form else ran in (1, 2), (form, ran)      # the forced form is the one that ran
             if want is None:
                 assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d), (form, groups, splits)
             else:

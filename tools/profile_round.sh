@@ -8,7 +8,7 @@
 #   <tag>_pmc_sq_dense.json       SQ counters + clock of the fp32 dense path (one 8192-row pass per launch)
 #   <tag>_pmc_sq_sparse.json      ... of the sparse first layer (16384 rows)
 #   <tag>_pmc_gemm16_f16.json / _f16x2.json   ... of the fp16 kernels (one 32768-row pass)
-#   <tag>_pmc_knn_c3.json / _c4rank.json      ... of the search at 100k x 100k and at one rank's 125k x 1M
+#   <tag>_pmc_knn_c3.json / _c4rank.json      ... of the search at 100k x 100k and at one rank's 125k x 1M (+ _c4rank_kstep.json: the collect's other norm form)
 set -u
 cd "$(dirname "$0")/.."
 tag=${1:-r03}
@@ -32,4 +32,6 @@ for dt in f16 f16x2; do
 done
 python3 tools/pmc_run.py "$dst/${tag}_pmc_knn_c3.json" knn_ --groups sq -- python3 $root/tools/knn_bench.py 100000 64 15 100000 2 2>&1 | tail -n 8
 python3 tools/pmc_run.py "$dst/${tag}_pmc_knn_c4rank.json" knn_ --groups sq -- python3 $root/tools/knn_bench.py 1000000 64 15 125000 1 2>&1 | tail -n 8
+# the same search with the collect's norm K-step form forced (the library picks the accumulator form at this shape since round 4)
+CC_KNN_COLLECT_NORM_FORM=1 python3 tools/pmc_run.py "$dst/${tag}_pmc_knn_c4rank_kstep.json" knn_collect --groups sq -- python3 $root/tools/knn_bench.py 1000000 64 15 125000 1 2>&1 | tail -n 3
 ls -la "$dst"
