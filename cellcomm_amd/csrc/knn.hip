@@ -1075,7 +1075,10 @@ __device__ __forceinline__ void wavebufc_flush(WaveBufC &wb, const float *__rest
     const int64_t ql = q0 + wb.qr[i];
     if (ql < n_q) {
       const unsigned cand = wb.cand[i];
-      const float fine = fine_dist_batched(x + (q_begin + ql) * d, x + (int64_t)cand * d, d, vec);   // = fine_dist, bit for bit
+      // (fine_dist, not its batched form: 64 registers of loads in flight here were the register peak of the whole kernel —
+      // 168 -> 155 / 159 -> 132 without them — and the flush is rare enough that the one-quad-at-a-time form costs nothing:
+      // measured 1-3 % FASTER at every shape, tools/experiments/knn_w4b_ab.sh)
+      const float fine = fine_dist(x + (q_begin + ql) * d, x + (int64_t)cand * d, d, vec);
       if (fine <= T[ql]) {
         const int pos = atomicAdd(cursor + ql, 1);
         if (pos < cap) buf[ql * cap + pos] = ((u64)f32_to_ordered(fine) << 32) | (u64)cand;
@@ -1164,8 +1167,8 @@ __device__ __forceinline__ void collect16c_park(unsigned long long m64, int b0, 
 //    parking call per pair of blocks — with no per-tile compare, ballot or branch;
 //  * when hits are rare (min_first: N large against the list size) the straight path first ORs ALL accumulators of a
 //    block pair (v_or3 tree) and rejects the pair with ONE ballot; only a pair with a hit looks at its tiles;
-//  * the parked pairs are re-evaluated with 32 coordinates in flight (fine_dist_batched: the same sum, bit for bit)
-//    instead of one dependent round trip per 4 coordinates.
+//  * (the parked pairs were re-evaluated with 32 coordinates in flight for a while — fine_dist_batched, still what the
+//    threshold kernel uses; the round's last session went back to fine_dist here: see wavebufc_flush.)
 constexpr int C16C_NSTAGE = 4;
 constexpr int C16C_PAD_BLOCKS = 4;   // >= the largest CB: padding blocks behind the panel (knn_pack16_kernel fills them as "no candidate")
 // The stage barrier of the ring as the bare instruction: __syncthreads() carries a fence that waits vmcnt(0) while
