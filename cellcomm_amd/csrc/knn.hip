@@ -1254,6 +1254,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void knn_collect16c_kerne
   const int b_hi = (b_lo + NBs < NB) ? b_lo + NBs : NB;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  __builtin_assume(wave >= 0 && wave < NW);   // the request loop's "does this wave have a row i" tests fold for all but the last i
   const int r = lane & 31, h = lane >> 5;
   const float s2 = s * s;
   const int vec = (d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) ? 1 : 0;
@@ -1277,15 +1278,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void knn_collect16c_kerne
       roff[i] = ((u / ND) * NT + u % ND) * 1024;
     }
   }
-  auto issue = [&](int slot) {
+  auto issue = [&](int slot_u) {   // slot_u = slot · STAGE_U (running offsets below: no multiplication per stage)
 #pragma unroll
     for (int i = 0; i < DPS; ++i)
       if (wave + NW * i < NU) {   // wave-uniform
         if constexpr (CN) {
-          if (wave + NW * i == NU - 1) CC_KNN_GLDS16(nsrc + voff, stage + (slot * STAGE_U + (NU - 1) * 64));
-          else CC_KNN_GLDS16(gsrc + roff[i] + voff, stage + (slot * STAGE_U + (wave + NW * i) * 64));
+          if (wave + NW * i == NU - 1) CC_KNN_GLDS16(nsrc + voff, stage + (slot_u + (NU - 1) * 64));
+          else CC_KNN_GLDS16(gsrc + roff[i] + voff, stage + (slot_u + (wave + NW * i) * 64));
         } else {
-          CC_KNN_GLDS16(gsrc + i * (NW * 1024) + voff, stage + (slot * STAGE_U + (wave + NW * i) * 64));
+          CC_KNN_GLDS16(gsrc + i * (NW * 1024) + voff, stage + (slot_u + (wave + NW * i) * 64));
         }
       }
     if constexpr (CN) { gsrc += CB * NT * 1024; nsrc += CB * 128; }
@@ -1299,7 +1300,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void knn_collect16c_kerne
   };
 #pragma unroll
   for (int p = 0; p < NSTAGE - 1; ++p)
-    if (p < nstages) issue(p);   // under the set-up below
+    if (p < nstages) issue(p * STAGE_U);   // under the set-up below
 
   h8 bqh[QW][TU];
   float thr[QW];   // CN: Ts − s²‖q−μ‖², a pair passes when its accumulator is below
@@ -1342,6 +1343,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void knn_collect16c_kerne
   const int sp_lo = include_self ? 0x7fffffff : (int)((q_begin + q0) >> 5);
   const int sp_hi = include_self ? -1 : (int)((q_begin + q0 + QPW - 1) >> 5);
   const int tail_blk = (N & 31) ? NB - 1 : 0x7fffffff;   // the partly filled last block, if any
+  // The same three conditions as stage indices, once per workgroup instead of ~20 scalar instructions per stage (the
+  // collect's time follows its instruction count, tools/experiments/README.md): stage st (blocks b_lo + st·CB ..) is
+  // plain when st < st_end (all its blocks inside the range and in front of a partly filled last block) and it holds
+  // none of this wave's own queries, st outside [sp_first, sp_first + sp_span].
+  auto floor_div = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+  const int lim = (b_hi < tail_blk ? b_hi : tail_blk) - b_lo;
+  const int st_end = lim > 0 ? lim / CB : 0;
+  const int sp_a = floor_div(sp_lo - b_lo, CB), sp_b = floor_div(sp_hi - b_lo, CB);
+  const int sp_first = sp_b >= sp_a ? sp_a : 0x7fffffff;          // empty (self pairs admitted): no stage matches
+  const unsigned sp_span = sp_b >= sp_a ? (unsigned)(sp_b - sp_a) : 0u;
   WaveBufC wb;
   wb.cand = reinterpret_cast<unsigned *>(smem + sizeof(h8) * NSTAGE * STAGE_U) + wave * COL_WB;
   wb.qr = reinterpret_cast<int *>(smem + sizeof(h8) * NSTAGE * STAGE_U + sizeof(unsigned) * NW * COL_WB) + wave * COL_WB;
@@ -1356,15 +1367,15 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void knn_collect16c_kerne
   wait_stages(nstages >= NSTAGE - 1);
   knn_stage_barrier();
 
-  int slot = 0;
+  int rd_u = 0, wr_u = (NSTAGE - 1) * STAGE_U;   // unit offsets of the slot read now and of the slot refilled now = (slot + NSTAGE - 1) % NSTAGE
   for (int st = 0; st < nstages; ++st) {
     // the slot written now was read one stage ago, and every wave is past that barrier
     const bool ahead = st + NSTAGE - 1 < nstages;
-    if (ahead) issue(slot >= 1 ? slot - 1 : NSTAGE - 1);   // (slot + NSTAGE - 1) % NSTAGE
+    if (ahead) issue(wr_u);
     // (CBM > 1: the stage is worked off in CBM parts of CBH blocks, so that only a part's fragments are in registers)
 #pragma unroll
     for (int hf = 0; hf < CBM; ++hf) {
-    const h8 *sbuf = stage + slot * STAGE_U + hf * CBH * HU + lane;
+    const h8 *sbuf = stage + rd_u + hf * CBH * HU + lane;
     h8 ah[CBH][TU];
 #pragma unroll
     for (int cb = 0; cb < CBH; ++cb)
@@ -1372,7 +1383,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void knn_collect16c_kerne
       for (int t = 0; t < TU; ++t) ah[cb][t] = sbuf[cb * HU + t * 64];
     // CN: what the accumulators of block cb start from — entry e of lane (r, h) is candidate (e & 3) + 8 (e >> 2) + 4 h:
     // four runs of four consecutive floats of the block's 32 (every lane of a half reads the same 16 bytes)
-    const f32x4 *nbuf = reinterpret_cast<const f32x4 *>(stage + slot * STAGE_U + (NU - 1) * 64) + hf * CBH * 8 + h;
+    const f32x4 *nbuf = reinterpret_cast<const f32x4 *>(stage + rd_u + (NU - 1) * 64) + hf * CBH * 8 + h;
     // (read inside the path that uses them: hoisted beside the fragment reads they stay live across the masked path
     // and the kernel spills)
     auto cinit = [&](int cb) {
@@ -1386,7 +1397,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void knn_collect16c_kerne
     };
     const int b0 = b_lo + st * CB + hf * CBH;
     // wave-uniform: no block of this stage needs a mask (own queries, padding rows) and all of them lie in the range
-    const bool plain = b0 + CBH <= b_hi && (b0 > sp_hi || b0 + CBH <= sp_lo) && b0 + CBH <= tail_blk;
+    const bool plain = CBM == 1 ? (st < st_end && (unsigned)(st - sp_first) > sp_span)
+                                : (b0 + CBH <= b_hi && (b0 > sp_hi || b0 + CBH <= sp_lo) && b0 + CBH <= tail_blk);
     if (plain) {
 #pragma unroll
       for (int pb = 0; pb < CBH; pb += PB) {
@@ -1492,7 +1504,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 3 : 1) void knn_collect16c_kerne
     // the next stage's data must have landed (in the tail fewer stages are in flight than the count assumes)
     wait_stages(ahead);
     knn_stage_barrier();
-    slot = slot == NSTAGE - 1 ? 0 : slot + 1;
+    rd_u = rd_u == (NSTAGE - 1) * STAGE_U ? 0 : rd_u + STAGE_U;
+    wr_u = wr_u == (NSTAGE - 1) * STAGE_U ? 0 : wr_u + STAGE_U;
   }
   wavebufc_flush(wb, x, d, vec, q_begin, T, buf, cursor, q0, n_q, cap, lane);
 }
