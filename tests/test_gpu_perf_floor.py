@@ -45,7 +45,9 @@ def floors():
 def test_floors_follow_the_tracked_profile():
     name, f = floors()
     assert re.match(r'r\d+_bench_line_under_rocprof\.json', name)
-    assert f['gemm_l1'] >= 125e12 and f['gemm_l2'] >= 125e12 and f['gather'] >= 5.5e12 and f['knn_ms'] <= 4.4
+    # sanity of the tracked file itself (a truncated or mis-keyed line must not turn the floors off); the gather of the
+    # tracked runs has been 5.98-6.20 TB/s under rocprofv3, so its bound sits below 0.92 x the lowest of them
+    assert f['gemm_l1'] >= 125e12 and f['gemm_l2'] >= 125e12 and f['gather'] >= 5.3e12 and f['knn_ms'] <= 4.4
     assert f['f16'] >= 1250e12 and f['f16x2'] >= 720e12 and f['sparse'] >= 31e12
 
 
