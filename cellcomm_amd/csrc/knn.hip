@@ -107,28 +107,54 @@ __global__ void knn_mean_kernel(const double *__restrict__ partial, int64_t N, i
 __device__ __forceinline__ float centred(float x, float mu) { return __fsub_rn(x, mu); }
 
 // ---- norms of the centred points -----------------------------------------------------
-__global__ void knn_norm_kernel(const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d,
-                                float *__restrict__ norms, unsigned *__restrict__ maxnorm_bits) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  double s = 0.0;
-  float amax = 0.f;
-  if (i < N) {
-    for (int t = 0; t < d; ++t) {
-      const float y = centred(x[i * d + t], mu[t]);
-      amax = fmaxf(amax, fabsf(y));
-      s += (double)y * (double)y;
+// One row per thread, float64 accumulation in coordinate order (what every later stage assumes of norms[]).  Round 4,
+// last session: the kernel took 0.93 ms for 1M x 64 (15x its HBM time, 4 % of a rank's search of configs[3]) — one
+// 4-byte load per coordinate and lane, and two same-address atomics per WAVE (31 000 of them at 1M rows).  Now 16-byte
+// loads where the rows allow them, a grid-stride loop over at most NORM_BLOCKS blocks, and one pair of atomics per BLOCK.
+constexpr int NORM_BLOCKS = 2048;
+__global__ __launch_bounds__(256) void knn_norm_kernel(const float *__restrict__ x, const float *__restrict__ mu, int64_t N, int d,
+                                                       float *__restrict__ norms, unsigned *__restrict__ maxnorm_bits) {
+  __shared__ unsigned red[2][4];
+  const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(mu) & 15) == 0;
+  unsigned fb = 0u, ab = 0u;   // non-negative floats order as uints (a NaN's bits win: the scale check rejects it)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < N; i += (int64_t)gridDim.x * blockDim.x) {
+    double s = 0.0;
+    float amax = 0.f;
+    const float *row = x + i * d;
+    if (vec) {
+      for (int t = 0; t < d; t += 4) {
+        const float4 v = *reinterpret_cast<const float4 *>(row + t), m = *reinterpret_cast<const float4 *>(mu + t);
+        float y = centred(v.x, m.x); amax = fmaxf(amax, fabsf(y)); s += (double)y * (double)y;
+        y = centred(v.y, m.y); amax = fmaxf(amax, fabsf(y)); s += (double)y * (double)y;
+        y = centred(v.z, m.z); amax = fmaxf(amax, fabsf(y)); s += (double)y * (double)y;
+        y = centred(v.w, m.w); amax = fmaxf(amax, fabsf(y)); s += (double)y * (double)y;
+      }
+    } else {
+      for (int t = 0; t < d; ++t) {
+        const float y = centred(row[t], mu[t]);
+        amax = fmaxf(amax, fabsf(y));
+        s += (double)y * (double)y;
+      }
     }
-    norms[i] = (float)s;
+    const float sf = (float)s;
+    norms[i] = sf;
+    const unsigned f1 = __float_as_uint(sf), a1 = __float_as_uint(amax);
+    fb = f1 > fb ? f1 : fb;
+    ab = a1 > ab ? a1 : ab;
   }
-  // one pair of atomics per wave; non-negative floats order as uints (a NaN's bits win: the scale check rejects it)
-  unsigned fb = i < N ? __float_as_uint((float)s) : 0u, ab = i < N ? __float_as_uint(amax) : 0u;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     const unsigned f2 = __shfl_xor(fb, o), a2 = __shfl_xor(ab, o);
     fb = f2 > fb ? f2 : fb;
     ab = a2 > ab ? a2 : ab;
   }
-  if ((threadIdx.x & 63) == 0) {
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = fb; red[1][threadIdx.x >> 6] = ab; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) {
+      fb = red[0][w] > fb ? red[0][w] : fb;
+      ab = red[1][w] > ab ? red[1][w] : ab;
+    }
     atomicMax(maxnorm_bits, fb);
     atomicMax(maxnorm_bits + 1, ab);      // largest |centred coordinate| (scale of the fp16 panels)
   }
@@ -2240,8 +2266,8 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
                        partial.as<double>());
     hipLaunchKernelGGL(knn_mean_kernel, dim3(1), dim3(mean_threads, MEAN_PARTS), 0, stream(), partial.as<double>(), N, d,
                        mu.as<float>());
-    hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)ceil_div(N, 256)), dim3(256), 0, stream(), d_x,
-                       mu.as<float>(), N, d, norms.as<float>(), maxn.as<unsigned>());
+    hipLaunchKernelGGL(knn_norm_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(N, 256), NORM_BLOCKS)), dim3(256), 0,
+                       stream(), d_x, mu.as<float>(), N, d, norms.as<float>(), maxn.as<unsigned>());
     CC_HIP(hipGetLastError());
   }
   // the fp32 panels are packed only if an fp32 tile kernel runs (the fp16 route has its own panels)
