@@ -33,6 +33,7 @@
 //  3. fallback — uncertified queries (dense duplicates / near ties) are rescanned
 //     against all candidates in float64, bounded by their stage-2 k-th key.
 #include "common.h"
+#include <sys/mman.h>
 
 namespace cc {
 
@@ -2128,6 +2129,22 @@ static bool host_ptr_is_pinned(const void *p) {
   return attr.type == hipMemoryTypeHost;
 }
 
+// Fresh pageable result arrays fault their pages in on the first store — ~0.25 us per 4 KiB page, a large part of the
+// host copy below when the caller allocates new arrays per call (numpy does).  knn_run populates them while the search
+// kernels run: one madvise(MADV_POPULATE_WRITE) per array (contents untouched), or a same-value store per page where
+// the kernel predates that advice.
+static void host_populate(void *p, size_t bytes) {
+  if (!p || !bytes) return;
+  const uintptr_t page = 4096, lo = reinterpret_cast<uintptr_t>(p) & ~(page - 1),
+                  hi = (reinterpret_cast<uintptr_t>(p) + bytes + page - 1) & ~(page - 1);
+#ifdef MADV_POPULATE_WRITE
+  if (madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_POPULATE_WRITE) == 0) return;
+#endif
+  volatile char *c = static_cast<volatile char *>(p);
+  for (size_t off = 0; off < bytes; off += page) c[off] = c[off];
+  c[bytes - 1] = c[bytes - 1];
+}
+
 static int copy_results(KnnWorkspace &ws, const void *d_idx, const void *d_dist, size_t bytes_each, void *h_idx, void *h_dist) {
   if (host_ptr_is_pinned(h_idx) && host_ptr_is_pinned(h_dist)) {
     CC_HIP(hipMemcpyAsync(h_idx, d_idx, bytes_each, hipMemcpyDeviceToHost, stream()));
@@ -2476,6 +2493,10 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
                        odist.as<float>(), nflag.as<int>(), flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>());
     CC_HIP(hipGetLastError());
   }
+  // (before the flag readback: a device-to-host copy into pageable memory — the flag below — blocks in the runtime
+  // until the stream has drained, so this is the last point where the host is free while the kernels run)
+  if (!host_ptr_is_pinned(h_idx)) host_populate(h_idx, sizeof(int32_t) * (size_t)(n_q * k));
+  if (!host_ptr_is_pinned(h_dist)) host_populate(h_dist, sizeof(float) * (size_t)(n_q * k));
   int h_nflag = 0;
   CC_HIP(hipMemcpyAsync(&h_nflag, nflag.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
   CC_HIP(hipStreamSynchronize(stream()));

@@ -293,6 +293,34 @@ def test_query_subrange_on_device(hip, oracle_built):
     assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d)
 
 
+def test_results_into_pageable_pinned_and_unaligned_arrays(hip, oracle_built):
+    """Pageable result arrays are populated under the kernels and filled through the pinned bounce buffer; pinned ones
+    take the DMA directly.  Same bits either way, for arrays that start in the middle of a page too, and not a byte
+    outside the arrays changes (the populate works on whole pages around them)."""
+    import torch
+    n, d, k = 9000, 64, 15
+    x = np.random.default_rng(77).random((n, d), dtype=np.float32)
+    t = torch.from_numpy(x).cuda()
+    torch.cuda.synchronize()
+    want_i, want_d = ko.knn(x, k)
+    idx, dist = hipknn.knn_graph_device(t.data_ptr(), n, d, k)                       # fresh pageable arrays
+    assert np.array_equal(idx, want_i) and np.array_equal(dist, want_d)
+    pin_i = torch.empty((n, k), dtype=torch.int32).pin_memory()
+    pin_d = torch.empty((n, k), dtype=torch.float32).pin_memory()
+    hipknn.knn_graph_device(t.data_ptr(), n, d, k, out=(pin_i.numpy(), pin_d.numpy()))
+    assert np.array_equal(pin_i.numpy(), want_i) and np.array_equal(pin_d.numpy(), want_d)
+    words, lead = n * k, 1237                                                       # 4948 bytes into the buffer
+    buf_i = np.full(words + 3000, -7, dtype=np.int32)
+    buf_d = np.full(words + 3000, -7.0, dtype=np.float32)
+    out_i, out_d = buf_i[lead:lead + words].reshape(n, k), buf_d[lead:lead + words].reshape(n, k)
+    hipknn.knn_graph_device(t.data_ptr(), n, d, k, out=(out_i, out_d))
+    assert np.array_equal(out_i, want_i) and np.array_equal(out_d, want_d)
+    for buf, fill in ((buf_i, -7), (buf_d, -7.0)):
+        assert np.all(buf[:lead] == fill) and np.all(buf[lead + words:] == fill)
+    idx, dist = hipknn.knn_graph_device(t.data_ptr(), n, d, k, q_begin=8999, n_q=1)  # a 60-byte result
+    assert np.array_equal(idx, want_i[8999:]) and np.array_equal(dist, want_d[8999:])
+
+
 def test_sample_keys_hold_more_tiles_than_one_range(hip, oracle_built):
     """A sample key carries the index of its tile in 13 bits: a candidate range of more than 8192 sampled tiles is split
     (here: 300k candidates with EVERY block sampled = 9375 tiles).  512 queries from the middle, against the oracle."""
