@@ -187,8 +187,8 @@ void cc_mtx_free(void *mtx);
  * default workspace (grow-only scratch, released by cc_shutdown; options set on it with
  * cc_knn_set_option(NULL, ..) outlive a shutdown).  host_idx / host_dist may be pageable or pinned (hipHostMalloc /
  * hipHostRegister / torch pin_memory): pinned arrays take the DMA directly, pageable ones are filled through a pinned
- * bounce buffer of the workspace (ABI v105) and are WRITTEN before the search has finished (their pages are populated
- * under the kernels; contents are unspecified if the call fails).  The search needs about 5 KB of device scratch per query at k = 15
+ * bounce buffer of the workspace (ABI v105); their pages are populated (faulted in for writing, contents unchanged)
+ * while the search kernels run, so both arrays must be writable for the whole call.  The search needs about 5 KB of device scratch per query at k = 15
  * (n_q = 1 000 000: 5 GB), 12 KB at k = 50. */
 int cc_knn_l2(const float *host_x, int64_t n_total, int d, int k, int include_self,
               int32_t *host_idx, float *host_dist);
