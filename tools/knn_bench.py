@@ -36,5 +36,14 @@ for _ in range(reps):
     knn_graph_device(x.data_ptr(), n, d, k, 0, nq)
 t1 = time.perf_counter()
 p = _lib.profile_snapshot()
-print(f'n={n} d={d} k={k} nq={nq}: {1e3*(t1-t0)/reps:.2f} ms/call', {kk: round(v['ms']/reps, 3) for kk, v in p.items() if v['launches']},
+line_host = ''
+if nq == n and os.environ.get('CC_KNN_HOST_LEG', '1') != '0':   # the same search from HOST points (cc_knn_l2, what cc.knn_graph(ndarray) calls)
+    import cellcomm_amd as cc
+    xh = x.cpu().numpy()
+    cc.knn_graph(xh, k)
+    th = time.perf_counter()
+    for _ in range(reps):
+        cc.knn_graph(xh, k)
+    line_host = f' (host points: {1e3*(time.perf_counter()-th)/reps:.2f} ms/call)'
+print(f'n={n} d={d} k={k} nq={nq}: {1e3*(t1-t0)/reps:.2f} ms/call' + line_host, {kk: round(v['ms']/reps, 3) for kk, v in p.items() if v['launches']},
       'fallback', _lib.lib().cc_knn_last_fallback_count())
