@@ -9,6 +9,6 @@ import csv, glob, sys
 tag = sys.argv[1]
 f = glob.glob(f'/tmp/kst_{tag}/**/*kernel_stats.csv', recursive=True)
 rows = list(csv.DictReader(open(f[0])))
-for r in rows[:8]:
+for r in rows[:14]:
     print(tag, r['Name'][:60], 'calls', r['Calls'], 'avg_us %.1f' % (float(r['AverageNs']) / 1e3))
 PY
