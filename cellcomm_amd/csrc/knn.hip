@@ -978,13 +978,17 @@ __global__ __launch_bounds__(64 * SMP_WAVES, 2) void knn_sample16_kernel(
 // wave per query: the m-th smallest key by bisection over its bits, counting with ballots; the lanes holding keys at or
 // below it (m of them, more on ties) evaluate their candidate's distance directly in fp32, T = the largest of those.
 // Fewer than m real keys: T = +inf (the collect lists everything it can hold; stage 3 takes over if that overflows).
+// MAXR = key registers per lane the instance is unrolled for (>= n / 64).  The key loops are unrolled MAXR times with a
+// `j < nreg` test per step, and hipcc keeps most of a skipped step's vector work (selects instead of branches): the
+// single 16-register instance issued 903 vector + 576 scalar instructions per query at C3, whose queries hold n = 192 keys
+// (3 registers per lane) — `tools/experiments/README.md`, the round's re-entry session.
+template <int MAXR>
 __global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const unsigned *__restrict__ skey, const float *__restrict__ x,
                                                                  int d, int64_t q_begin, int64_t n_q, int n, int m, int NSET,
                                                                  int64_t NBs, int bstride, float *__restrict__ T) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int64_t ql = (int64_t)blockIdx.x * 4 + wave;
   if (ql >= n_q) return;
-  constexpr int MAXR = 16;
   unsigned key[MAXR];
   const int nreg = n / 64;
 #pragma unroll
@@ -1029,7 +1033,7 @@ __global__ __launch_bounds__(256) void knn_slot_threshold_kernel(const unsigned 
     const int per_range = NSET * 32;
     // The chosen keys sit anywhere in the wave's registers (a lane may hold several, most hold none): they are first
     // compacted into a wave-private list, then ONE lane per candidate evaluates its distance — all of them at once
-    // instead of one dependent gather per register row (round 3: 0.30 -> 0.23 ms per 100k queries; the rest is the bisection).  The distance of a
+    // instead of one dependent gather per register row (round 3: 0.30 -> 0.23 ms per 100k queries; round 4: 0.17 with the key loops unrolled for the registers a query really has).  The distance of a
     // candidate is the same sequential fp32 sum as before (the collect's final test compares against exactly that).
     __shared__ int64_t chosen[4][64];
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -2425,8 +2429,19 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
         if ((rc = run_sample16(ND16, NSET, QWS, P16.as<h8>(), sa, maxn.as<unsigned>(), scale16, SS, NBss, SAMPLE,
                                smin.as<unsigned>())))
           return rc;
-        hipLaunchKernelGGL(knn_slot_threshold_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), 0, stream(),
-                           smin.as<unsigned>(), d_x, d, q_begin, n_q, nslots, m, NSET, NBss, SAMPLE, Tq.as<float>());
+        CC_REQUIRE(nslots % 64 == 0 && nslots <= 16 * 64, "knn: %d sample slots per query", nslots);
+#define CC_SLOT_THR(R)                                                                                             \
+  hipLaunchKernelGGL(knn_slot_threshold_kernel<R>, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), 0, stream(),       \
+                     smin.as<unsigned>(), d_x, d, q_begin, n_q, nslots, m, NSET, NBss, SAMPLE, Tq.as<float>())
+        const int key_regs = nslots / 64;
+        if (key_regs <= 1) CC_SLOT_THR(1);
+        else if (key_regs <= 2) CC_SLOT_THR(2);
+        else if (key_regs <= 3) CC_SLOT_THR(3);
+        else if (key_regs <= 4) CC_SLOT_THR(4);
+        else if (key_regs <= 6) CC_SLOT_THR(6);
+        else if (key_regs <= 8) CC_SLOT_THR(8);
+        else CC_SLOT_THR(16);
+#undef CC_SLOT_THR
       } else {
         // fp32 route: select with m-entry LDS lists over the sampled blocks, T = the m-th best of the sample
 #ifndef CC_KNN_SAMPLE_SPARE
