@@ -3,7 +3,7 @@
 
   python3 tools/configs_table.py <out.json>        (e.g. profiles/r03_configs.json)
 
-Each row is a fresh `bench.py` process (3 steps, 1 warm-up, no CPU baseline, no alt legs) reduced to the fields the
+Each row is a fresh `bench.py` process (10 steps after 2 warm-ups; 3 after 1 for the rows above 100k cells; no CPU baseline, no alt legs) reduced to the fields the
 DESIGN.md table quotes, plus — for the two sharded configs — one rank's kNN call against ALL candidates of the
 config (tools/knn_bench.py: synthetic encodings already in HBM), which the one-GPU bench line cannot contain.
 Nothing here feeds bench.py's `value`.
@@ -41,7 +41,10 @@ KNN_ROWS = [
 
 
 def bench_row(label, flags):
-    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3', '--warmup', '1', '--no-cpu-baseline', '--no-alt'] + flags
+    # (short steps take 10 timed steps: over 3, one hiccup of a few ms in a 10 ms step moved configs[1]'s row by 17 %)
+    long_step = '--cells' in flags and int(flags[flags.index('--cells') + 1]) > 100000
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--steps', '3' if long_step else '10', '--warmup', '1' if long_step else '2',
+           '--no-cpu-baseline', '--no-alt'] + flags
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     if proc.returncode != 0:
         return {'label': label, 'flags': flags, 'error': proc.stderr[-800:]}
