@@ -1684,7 +1684,10 @@ __device__ __forceinline__ bool key_less(double da, int ia, double db, int ib) {
 }
 
 // ---- stage 2: rerank + certificate ----------------------------------------------------
-// one wave per query; dynamic LDS per wave: double xq[d], double dd[KP], int ii[KP]
+// one wave per query; dynamic LDS per query: double xq[d], double dd[KP], int ii[KP].  HALF (KP <= 32, i.e. k <= 18: every
+// BASELINE config but configs[4]): a query has at most 32 survivors, one per lane, so a wave serves TWO queries with 32
+// lanes each instead of leaving half of itself idle through both phases; a query's arithmetic does not change.
+template <bool HALF>
 __global__ __launch_bounds__(256) void knn_rerank_kernel(
     const float *__restrict__ x, const float *__restrict__ norms, const unsigned *__restrict__ maxnorm_bits,
     int d, int64_t q_begin, int64_t n_q, const u64 *__restrict__ keys, const int *__restrict__ cnts,
@@ -1693,26 +1696,27 @@ __global__ __launch_bounds__(256) void knn_rerank_kernel(
     int *__restrict__ nflag, int *__restrict__ flagged, double *__restrict__ bound_d,
     int *__restrict__ bound_i) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int64_t ql = (int64_t)blockIdx.x * 4 + wave;
+  constexpr int W = HALF ? 32 : 64;   // lanes per query
+  const int slot = threadIdx.x / W, lane = threadIdx.x % W;
+  const int64_t ql = (int64_t)blockIdx.x * (256 / W) + slot;
   if (ql >= n_q) return;
   const size_t per_wave = sizeof(double) * (size_t)(d + KP) + sizeof(int) * (size_t)KP;
-  char *base = smem + (size_t)wave * ((per_wave + 15) / 16 * 16);
+  char *base = smem + (size_t)slot * ((per_wave + 15) / 16 * 16);
   double *xq = reinterpret_cast<double *>(base);
   double *dd = xq + d;
   int *ii = reinterpret_cast<int *>(dd + KP);
   const int64_t q = q_begin + ql;
-  for (int t = lane; t < d; t += 64) xq[t] = (double)x[q * d + t];
-  __builtin_amdgcn_wave_barrier();
+  for (int t = lane; t < d; t += W) xq[t] = (double)x[q * d + t];
+  __builtin_amdgcn_wave_barrier();   // (a query's lanes sit in one wave, whose LDS accesses complete in order)
   const int c = cnts[ql];
   const bool vec = d % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0;
-  for (int j = lane; j < c; j += 64) {
+  for (int j = lane; j < c; j += W) {
     const int cand = (int)(unsigned)(keys[ql * KP + j] & 0xffffffffull);
     dd[j] = vec ? exact_dist_vec4(xq, x + (int64_t)cand * d, d) : exact_dist(xq, x + (int64_t)cand * d, d);
     ii[j] = cand;
   }
   __builtin_amdgcn_wave_barrier();
-  for (int j = lane; j < c; j += 64) {
+  for (int j = lane; j < c; j += W) {
     const double dj = dd[j];
     const int ij = ii[j];
     int rk = 0;
@@ -2546,10 +2550,14 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
   {
     const size_t per_wave = (sizeof(double) * (size_t)(d + KP) + sizeof(int) * (size_t)KP + 15) / 16 * 16;
     ProfScope prof(CC_PROF_KNN_RERANK, 3.0 * (double)n_q * (double)KP * (double)d);
-    hipLaunchKernelGGL(knn_rerank_kernel, dim3((unsigned)ceil_div(n_q, 4)), dim3(256), per_wave * 4, stream(), d_x,
-                       norms.as<float>(), maxn.as<unsigned>(), d, q_begin, n_q, keys.as<u64>(), cnts.as<int>(),
-                       bound.as<float>(), KP, k, eps_coef, ws.force_fallback ? 1 : 0, oidx.as<int32_t>(),
-                       odist.as<float>(), nflag.as<int>(), flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>());
+#define CC_RERANK(HALFV, QPB)                                                                                          \
+  hipLaunchKernelGGL(knn_rerank_kernel<HALFV>, dim3((unsigned)ceil_div(n_q, QPB)), dim3(256), per_wave * QPB, stream(),  \
+                     d_x, norms.as<float>(), maxn.as<unsigned>(), d, q_begin, n_q, keys.as<u64>(), cnts.as<int>(),       \
+                     bound.as<float>(), KP, k, eps_coef, ws.force_fallback ? 1 : 0, oidx.as<int32_t>(),                  \
+                     odist.as<float>(), nflag.as<int>(), flagged.as<int>(), bnd_d.as<double>(), bnd_i.as<int>())
+    if (KP <= 32) CC_RERANK(true, 8);   // two queries per wave
+    else CC_RERANK(false, 4);
+#undef CC_RERANK
     CC_HIP(hipGetLastError());
   }
   // (before the flag readback: a device-to-host copy into pageable memory — the flag below — blocks in the runtime
