@@ -2180,6 +2180,15 @@ static bool host_ptr_is_pinned(const void *p) {
   }
   return attr.type == hipMemoryTypeHost;
 }
+// plain pageable host memory, i.e. nothing the HIP runtime knows (managed or device allocations are left alone)
+static bool host_ptr_is_plain(const void *p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return true;
+  }
+  return attr.type == hipMemoryTypeUnregistered;
+}
 
 // Fresh pageable result arrays fault their pages in on the first store — ~0.25 us per 4 KiB page, a large part of the
 // host copy below when the caller allocates new arrays per call (numpy does).  knn_run populates them while the search
@@ -2562,8 +2571,8 @@ int knn_run(KnnWorkspace *wsp, const float *d_x, int64_t N, int d, int64_t q_beg
   }
   // (before the flag readback: a device-to-host copy into pageable memory — the flag below — blocks in the runtime
   // until the stream has drained, so this is the last point where the host is free while the kernels run)
-  if (!host_ptr_is_pinned(h_idx)) host_populate(h_idx, sizeof(int32_t) * (size_t)(n_q * k));
-  if (!host_ptr_is_pinned(h_dist)) host_populate(h_dist, sizeof(float) * (size_t)(n_q * k));
+  if (host_ptr_is_plain(h_idx)) host_populate(h_idx, sizeof(int32_t) * (size_t)(n_q * k));
+  if (host_ptr_is_plain(h_dist)) host_populate(h_dist, sizeof(float) * (size_t)(n_q * k));
   int h_nflag = 0;
   CC_HIP(hipMemcpyAsync(&h_nflag, nflag.p, sizeof(int), hipMemcpyDeviceToHost, stream()));
   CC_HIP(hipStreamSynchronize(stream()));
